@@ -1,0 +1,134 @@
+/*
+ * tgru -- C ABI of the MI355X (gfx950) multi-layer GRU forward / BPTT library.
+ *
+ * The library sits behind the `torch.nn.GRU` module interface exactly as the reference exercises
+ * it: nn.GRU(input_size, hidden_size, num_layers, batch_first=True), bias, unidirectional,
+ * dropout 0 (outdated_files/TimeGANv1.py:35-38,115-118,194-197,272-275,351-354; scorer stack
+ * metrics/GeneralRNN.py:41-44), called on a PackedSequence and followed by pad_packed_sequence
+ * (outdated_files/TimeGANv1.py:56-65).  There is no FFI in the reference: the operator boundary
+ * is `_VF.gru(data, batch_sizes, hx, flat_weights, ...)` inside torch/nn/modules/rnn.py:1427-1437,
+ * and these entry points are what a binding for that operator would call.
+ *
+ * Conventions
+ *   - all tensors are fp32, dense, in device memory; the caller owns every buffer; the library
+ *     never allocates, frees or keeps a pointer after return; every launch goes to `stream`;
+ *     no entry point synchronises with the host.
+ *   - w_ih / w_hh / b_ih / b_hh (and their gradient twins) are HOST arrays of L DEVICE pointers,
+ *     one per layer, with torch's shapes: weight_ih_l{k} (3H, In_k), weight_hh_l{k} (3H, H),
+ *     bias_*_l{k} (3H); gate row blocks ordered r, z, n; In_0 = In, In_k = H for k > 0.
+ *   - layout of x / y / dy / dx:
+ *       TGRU_LAYOUT_TBF    (T, B, F) time-major (the library's native order),
+ *       TGRU_LAYOUT_BTF    (B, T, F) batch-major (batch_first=True),
+ *       TGRU_LAYOUT_PACKED rows packed like PackedSequence.data: row = toff[t] + b.
+ *   - lengths: device int32[B], sequence b runs for t < lengths[b]; must be non-increasing
+ *     (enforce_sorted=True) and in [1, T]; NULL means every sequence has length T.  Rows with
+ *     t >= lengths[b] of a TBF / BTF output are written as 0 (pad_packed_sequence with
+ *     padding_value 0), dx rows there are 0, h_n[l][b] is the state at t = lengths[b]-1.
+ *   - toff: device int32[T+1], prefix sum of PackedSequence.batch_sizes; required for
+ *     TGRU_LAYOUT_PACKED (together with lengths), ignored otherwise.
+ *   - return value: TGRU_OK or a negative TGRU_E_* code; tgru_error_string() names it.
+ */
+#ifndef TGRU_H
+#define TGRU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tgru_stream_t; /* a hipStream_t */
+
+enum {
+    TGRU_LAYOUT_TBF = 0,
+    TGRU_LAYOUT_BTF = 1,
+    TGRU_LAYOUT_PACKED = 2
+};
+
+enum {
+    TGRU_OK = 0,
+    TGRU_E_DIMS = -1,      /* a dimension is <= 0 or too large for 32-bit row indexing */
+    TGRU_E_NULL = -2,      /* a required pointer is NULL */
+    TGRU_E_LAYOUT = -3,    /* unknown layout, or PACKED without lengths / toff */
+    TGRU_E_ALIGN = -4,     /* a buffer is not 16-byte aligned */
+    TGRU_E_LAUNCH = -5,    /* a kernel launch failed; hipGetLastError() has the cause */
+    TGRU_E_NOGPU = -6      /* the current device is not a gfx950 GPU */
+};
+
+/* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */
+int tgru_version(void);
+
+/* Text for a TGRU_E_* code.  No reference counterpart. */
+const char *tgru_error_string(int code);
+
+/*
+ * Bytes of state the forward pass must save for tgru_backward (the analogue of the `reserve`
+ * that torch's fused RNN paths keep between aten::gru forward and its autograd backward):
+ * per layer the gate activations r, z, n and the candidate's hidden pre-activation
+ * W_hn h + b_hn, plus each layer's output sequence in time-major order.
+ */
+size_t tgru_reserve_bytes(int B, int T, int In, int H, int L, int layout);
+
+/* Bytes of scratch memory tgru_forward / tgru_backward need in `workspace`. */
+size_t tgru_forward_workspace_bytes(int B, int T, int In, int H, int L);
+size_t tgru_backward_workspace_bytes(int B, int T, int In, int H, int L);
+
+/*
+ * Multi-layer GRU forward.  Replaces nn.GRU.forward -> _VF.gru at
+ * outdated_files/TimeGANv1.py:61,139,220,299,376 together with the pack / pad calls around it
+ * (:56-59, :62-65), whose row reordering is folded into the kernels' addressing.
+ *
+ *   x        (rows, In) in `layout`
+ *   h0       (L, B, H) initial state, or NULL for zeros (the reference never passes hx)
+ *   y        (rows, H) in `layout`: the top layer's h_t for every step
+ *   h_n      (L, B, H) final state per layer, or NULL if not wanted
+ *   reserve  tgru_reserve_bytes() bytes, or NULL for inference (then tgru_backward cannot follow)
+ *   workspace tgru_forward_workspace_bytes() bytes
+ */
+int tgru_forward(const float *x, const float *h0,
+                 const int32_t *lengths, const int32_t *toff,
+                 const float *const *w_ih, const float *const *w_hh,
+                 const float *const *b_ih, const float *const *b_hh,
+                 float *y, float *h_n, float *reserve, float *workspace,
+                 int B, int T, int In, int H, int L, int layout,
+                 tgru_stream_t stream);
+
+/*
+ * Backprop-through-time of tgru_forward.  Replaces the autograd graph torch records under
+ * aten::gru and replays in loss.backward() (outdated_files/TimeGANv1.py:604,679,772,785,807).
+ *
+ *   dy       gradient of y in `layout`, or NULL for zeros
+ *   dh_n     gradient of h_n (L, B, H), or NULL for zeros
+ *   x, h0, y, reserve, weights: exactly what tgru_forward read and wrote
+ *   dx       (rows, In) in `layout`, or NULL when the input needs no gradient
+ *   dh0      (L, B, H), or NULL
+ *   dw_ih / dw_hh / db_ih / db_hh: host arrays of L device pointers; every buffer is
+ *            overwritten (accumulate == 0) or added to (accumulate != 0)
+ *   workspace tgru_backward_workspace_bytes() bytes
+ */
+int tgru_backward(const float *dy, const float *dh_n,
+                  const float *x, const float *h0, const float *y,
+                  const int32_t *lengths, const int32_t *toff,
+                  const float *const *w_ih, const float *const *w_hh,
+                  const float *const *b_ih, const float *const *b_hh,
+                  const float *reserve, float *workspace,
+                  float *dx, float *dh0,
+                  float *const *dw_ih, float *const *dw_hh,
+                  float *const *db_ih, float *const *db_hh,
+                  int B, int T, int In, int H, int L, int layout, int accumulate,
+                  tgru_stream_t stream);
+
+/*
+ * The batched input projection on its own:  out (M, N) = a (M, K) . w (N, K)^T + bias (N),
+ * fp32 MFMA GEMM.  This is the `x . W_ih^T + b_ih` term of the cell equations
+ * (torch/nn/modules/rnn.py:1191-1194) over all rows at once; exported so that callers and
+ * tests can reach the kernel directly.  bias may be NULL.
+ */
+int tgru_input_projection(const float *a, const float *w, const float *bias, float *out,
+                          int M, int N, int K, tgru_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGRU_H */

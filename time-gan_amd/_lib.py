@@ -1,0 +1,57 @@
+"""ctypes binding of libtgru.so, the C-ABI HIP library declared in include/tgru.h.
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtgru.so")
+
+LAYOUT_TBF = 0
+LAYOUT_BTF = 1
+LAYOUT_PACKED = 2
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/tgru.h one to one
+SIGNATURES = {
+    "tgru_version": (_i, []),
+    "tgru_error_string": (ctypes.c_char_p, [_i]),
+    "tgru_reserve_bytes": (ctypes.c_size_t, [_i] * 6),
+    "tgru_forward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
+    "tgru_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
+    "tgru_forward": (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
+    "tgru_backward": (_i, [_vp] * 19 + [_i] * 7 + [_vp]),
+    "tgru_input_projection": (_i, [_vp] * 4 + [_i] * 3 + [_vp]),
+}
+
+
+class TgruError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtgru.so once.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgruError(
+                f"{LIB_PATH} not found: the HIP library is not built "
+                "(run `make -C time-gan_amd/csrc`); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().tgru_error_string(code).decode()
+        raise TgruError(f"{what} failed: {msg} (code {code})")

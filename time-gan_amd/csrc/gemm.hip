@@ -1,0 +1,285 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32), LDS-tiled, register-staged double buffer.
+//
+// Used for every batched (non-recurrent) product of the GRU:
+//   gi   = X . W_ih^T + b_ih         (a_kc, b_kc)      rows = all (b,t) at once
+//   dX   = dGI . W_ih                (a_kc, !b_kc)
+//   dW_ih = dGI^T . X, dW_hh = dGH^T . H_prev   (!a_kc, !b_kc, split over the row dimension)
+#include "tgru_internal.h"
+
+namespace tgru {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
+    constexpr int LDA_S = BM + 4;
+    constexpr int LDB_S = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB_S];
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad wave tiling");
+    constexpr int SLOTS_A = BM * BK / 4;   // float4 slots per tile
+    constexpr int SLOTS_B = BN * BK / 4;
+    constexpr int PA = (SLOTS_A + NTHREADS - 1) / NTHREADS;
+    constexpr int PB = (SLOTS_B + NTHREADS - 1) / NTHREADS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    const bool b_vec = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.Bm) & 15) == 0);
+
+    // per-thread slot coordinates (constant over the k loop)
+    long a_base[PA];   // A_KC: element offset of (row, k=0) or -1; !A_KC: m index or -1
+    int a_r[PA], a_c[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int slot = tid + p * NTHREADS;
+        if (A_KC) {
+            a_r[p] = slot >> 2;           // tile row (m)
+            a_c[p] = (slot & 3) << 2;     // k offset inside the tile
+            const int m = m0 + a_r[p];
+            long r = -1;
+            if (slot < SLOTS_A && m < g.M) r = map_row(g.amap, m);
+            a_base[p] = (r < 0) ? -1 : r * g.lda;
+        } else {
+            a_r[p] = slot / (BM / 4);           // tile k row
+            a_c[p] = (slot % (BM / 4)) << 2;    // m offset inside the tile
+            a_base[p] = (slot < SLOTS_A) ? (long)(m0 + a_c[p]) : -1;
+        }
+    }
+    long b_base[PB];
+    int b_r[PB], b_c[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int slot = tid + p * NTHREADS;
+        if (B_KC) {
+            b_r[p] = slot >> 2;           // tile col (n)
+            b_c[p] = (slot & 3) << 2;
+            const int n = n0 + b_r[p];
+            b_base[p] = (slot < SLOTS_B && n < g.N) ? (long)n * g.ldb : -1;
+        } else {
+            b_r[p] = slot / (BN / 4);
+            b_c[p] = (slot % (BN / 4)) << 2;
+            b_base[p] = (slot < SLOTS_B) ? (long)(n0 + b_c[p]) : -1;
+        }
+    }
+
+    float4 ra[PA], rb[PB];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_base[p] >= 0) {
+                if (A_KC) {
+                    const int k = k0 + a_c[p];
+                    const float *src = g.A + a_base[p] + k;
+                    if (a_vec && k + 3 < kend) {
+                        v = *reinterpret_cast<const float4 *>(src);
+                    } else {
+                        if (k + 0 < kend) v.x = src[0];
+                        if (k + 1 < kend) v.y = src[1];
+                        if (k + 2 < kend) v.z = src[2];
+                        if (k + 3 < kend) v.w = src[3];
+                    }
+                } else {
+                    const int k = k0 + a_r[p];
+                    if (k < kend) {
+                        const long m = a_base[p];
+                        const float *src = g.A + (long)k * g.lda + m;
+                        if (a_vec && m + 3 < g.M) {
+                            v = *reinterpret_cast<const float4 *>(src);
+                        } else {
+                            if (m + 0 < g.M) v.x = src[0];
+                            if (m + 1 < g.M) v.y = src[1];
+                            if (m + 2 < g.M) v.z = src[2];
+                            if (m + 3 < g.M) v.w = src[3];
+                        }
+                    }
+                }
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_base[p] >= 0) {
+                if (B_KC) {
+                    const int k = k0 + b_c[p];
+                    const float *src = g.Bm + b_base[p] + k;
+                    if (b_vec && k + 3 < kend) {
+                        v = *reinterpret_cast<const float4 *>(src);
+                    } else {
+                        if (k + 0 < kend) v.x = src[0];
+                        if (k + 1 < kend) v.y = src[1];
+                        if (k + 2 < kend) v.z = src[2];
+                        if (k + 3 < kend) v.w = src[3];
+                    }
+                } else {
+                    const int k = k0 + b_r[p];
+                    const long krow = (k < kend) ? map_row(g.bmap, k) : -1L;
+                    if (krow >= 0) {
+                        const long n = b_base[p];
+                        const float *src = g.Bm + krow * g.ldb + n;
+                        if (b_vec && n + 3 < g.N) {
+                            v = *reinterpret_cast<const float4 *>(src);
+                        } else {
+                            if (n + 0 < g.N) v.x = src[0];
+                            if (n + 1 < g.N) v.y = src[1];
+                            if (n + 2 < g.N) v.z = src[2];
+                            if (n + 3 < g.N) v.w = src[3];
+                        }
+                    }
+                }
+            }
+            rb[p] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            if (tid + p * NTHREADS < SLOTS_A) {
+                if (A_KC) {
+                    As[buf][a_c[p] + 0][a_r[p]] = ra[p].x;
+                    As[buf][a_c[p] + 1][a_r[p]] = ra[p].y;
+                    As[buf][a_c[p] + 2][a_r[p]] = ra[p].z;
+                    As[buf][a_c[p] + 3][a_r[p]] = ra[p].w;
+                } else {
+                    *reinterpret_cast<float4 *>(&As[buf][a_r[p]][a_c[p]]) = ra[p];
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            if (tid + p * NTHREADS < SLOTS_B) {
+                if (B_KC) {
+                    Bs[buf][b_c[p] + 0][b_r[p]] = rb[p].x;
+                    Bs[buf][b_c[p] + 1][b_r[p]] = rb[p].y;
+                    Bs[buf][b_c[p] + 2][b_r[p]] = rb[p].z;
+                    Bs[buf][b_c[p] + 3][b_r[p]] = rb[p].w;
+                } else {
+                    *reinterpret_cast<float4 *>(&Bs[buf][b_r[p]][b_c[p]]) = rb[p];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int lrow = lane & 31;
+    const int lk = lane >> 5;
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][kk + lk][wm * WTM + i * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kk + lk][wn * WTN + j * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *Cz = g.C + (long)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m >= g.M) continue;
+            const long crow = map_row(g.cmap, m);
+            if (crow < 0) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + lrow;
+                if (n < g.N) {
+                    float v = acc[i][j][r];
+                    if (g.bias) v += g.bias[n];
+                    float *dst = Cz + crow * g.ldc + n;
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, nslabs);
+    dim3 block(NTHREADS);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, g);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, g);
+    else if (!a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    // narrow outputs get the 128x32 tile, everything else 128x128
+    const int waste128 = ((g.N + 127) / 128) * 128 - g.N;
+    const int waste32 = ((g.N + 31) / 32) * 32 - g.N;
+    const bool narrow = (g.N <= 96) || (waste128 * 4 > g.N && waste32 * 4 <= g.N);
+    if (narrow) return launch_cfg<128, 32, 4, 1>(g, a_kc, b_kc, nslabs, s);
+    return launch_cfg<128, 128, 2, 2>(g, a_kc, b_kc, nslabs, s);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slabs, long stride, int nslabs,
+                                                          float *out, long n, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int z = 0; z < nslabs; ++z) v += slabs[(long)z * stride + i];
+    if (accumulate) v += out[i];
+    out[i] = v;
+}
+
+hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float *out, long n,
+                              int accumulate, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, stride, nslabs, out,
+                       n, accumulate);
+    return hipGetLastError();
+}
+
+}  // namespace tgru

@@ -1,0 +1,306 @@
+// C ABI of the tgru library: argument checks, buffer carving and the per-layer launch sequence.
+#include "../../include/tgru.h"
+#include "tgru_internal.h"
+
+using namespace tgru;
+
+namespace {
+
+constexpr int kMaxHidden = 512;
+
+inline size_t align64(size_t floats) { return (floats + 63) & ~(size_t)63; }
+
+struct Dims {
+    int B, T, In, H, L, layout;
+    size_t TB() const { return (size_t)T * B; }
+    size_t TBH() const { return (size_t)T * B * H; }
+};
+
+int check_dims(int B, int T, int In, int H, int L, int layout) {
+    if (B <= 0 || T <= 0 || In <= 0 || H <= 0 || L <= 0) return TGRU_E_DIMS;
+    if (H > kMaxHidden) return TGRU_E_DIMS;
+    if ((long long)B * T >= (1LL << 31) / 4) return TGRU_E_DIMS;
+    if (layout != TGRU_LAYOUT_TBF && layout != TGRU_LAYOUT_BTF && layout != TGRU_LAYOUT_PACKED)
+        return TGRU_E_LAYOUT;
+    return TGRU_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
+size_t reserve_floats(const Dims &d) {
+    size_t n = (size_t)d.L * 4 * align64(d.TBH());
+    n += (size_t)(d.L - 1) * align64(d.TBH());
+    if (d.layout != TGRU_LAYOUT_TBF) n += align64(d.TBH());
+    return n;
+}
+float *reserve_gates(const Dims &d, float *r, int l) { return r + (size_t)l * 4 * align64(d.TBH()); }
+float *reserve_y(const Dims &d, float *r, int l) {   // l < L-1, or l == L-1 when layout != TBF
+    return r + (size_t)d.L * 4 * align64(d.TBH()) + (size_t)l * align64(d.TBH());
+}
+
+// forward workspace: gi | packed W_hh | two ping-pong layer outputs (inference without reserve)
+size_t fwd_ws_floats(const Dims &d) {
+    return align64(d.TB() * 3 * d.H) + align64(packed_whh_floats(d.H)) + 2 * align64(d.TBH());
+}
+
+int split_for(int M, int N, long K, int *kchunk) {
+    const int bn = (N <= 96) ? 32 : 128;
+    const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
+    long want = 768 / tiles;
+    if (want < 1) want = 1;
+    long maxs = K / 512;
+    if (maxs < 1) maxs = 1;
+    long ns = want < maxs ? want : maxs;
+    long kc = (K + ns - 1) / ns;
+    kc = (kc + 15) / 16 * 16;
+    if (kc < 16) kc = 16;
+    ns = (K + kc - 1) / kc;
+    if (ns < 1) ns = 1;
+    *kchunk = (int)kc;
+    return (int)ns;
+}
+
+// backward workspace: dg | 2 x dy ping-pong | packed W_hh^T | bias partials | split-K slabs
+struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, total; int max_slabs; };
+BwdWs bwd_ws(const Dims &d) {
+    BwdWs w;
+    size_t off = 0;
+    w.dg = off; off += align64(d.TB() * 4 * d.H);
+    w.dyb = off; off += 2 * align64(d.TB() * (size_t)(d.H > d.In ? d.H : d.In));
+    w.wtp = off; off += align64(packed_whh_floats(d.H));
+    w.dbp = off; off += align64((size_t)gru_batch_blocks(d.B) * 4 * d.H);
+    int kc;
+    const int widest = d.In > d.H ? d.In : d.H;
+    int ns = split_for(3 * d.H, widest, (long)d.TB(), &kc);
+    int ns2 = split_for(3 * d.H, d.H, (long)d.TB(), &kc);
+    int ns3 = split_for(3 * d.H, d.In, (long)d.TB(), &kc);
+    w.max_slabs = ns > ns2 ? ns : ns2;
+    if (ns3 > w.max_slabs) w.max_slabs = ns3;
+    w.slabs = off; off += align64((size_t)w.max_slabs * 3 * d.H * widest);
+    w.total = off;
+    return w;
+}
+
+RowMap ext_map(const Dims &d, const int32_t *toff) {
+    RowMap m;
+    m.mode = d.layout; m.B = d.B; m.T = d.T; m.toff = toff;
+    return m;
+}
+RowMap id_map(const Dims &d) {
+    RowMap m;
+    m.mode = 0; m.B = d.B; m.T = d.T; m.toff = nullptr;
+    return m;
+}
+
+#define TGRU_HIP(expr)                                   \
+    do {                                                 \
+        if ((expr) != hipSuccess) return TGRU_E_LAUNCH;  \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int tgru_version(void) { return 100; }
+
+const char *tgru_error_string(int code) {
+    switch (code) {
+    case TGRU_OK: return "ok";
+    case TGRU_E_DIMS: return "bad dimensions (all must be > 0, hidden_size <= 512, B*T < 2^29)";
+    case TGRU_E_NULL: return "a required pointer is NULL";
+    case TGRU_E_LAYOUT: return "unknown layout, or packed layout without lengths/toff";
+    case TGRU_E_ALIGN: return "a buffer is not 16-byte aligned";
+    case TGRU_E_LAUNCH: return "a kernel launch failed";
+    case TGRU_E_NOGPU: return "the current device is not a gfx950 GPU";
+    default: return "unknown error";
+    }
+}
+
+size_t tgru_reserve_bytes(int B, int T, int In, int H, int L, int layout) {
+    if (check_dims(B, T, In, H, L, layout) != TGRU_OK) return 0;
+    const Dims d{B, T, In, H, L, layout};
+    return reserve_floats(d) * sizeof(float);
+}
+
+size_t tgru_forward_workspace_bytes(int B, int T, int In, int H, int L) {
+    if (check_dims(B, T, In, H, L, TGRU_LAYOUT_TBF) != TGRU_OK) return 0;
+    const Dims d{B, T, In, H, L, TGRU_LAYOUT_TBF};
+    return fwd_ws_floats(d) * sizeof(float);
+}
+
+size_t tgru_backward_workspace_bytes(int B, int T, int In, int H, int L) {
+    if (check_dims(B, T, In, H, L, TGRU_LAYOUT_TBF) != TGRU_OK) return 0;
+    const Dims d{B, T, In, H, L, TGRU_LAYOUT_TBF};
+    return bwd_ws(d).total * sizeof(float);
+}
+
+int tgru_input_projection(const float *a, const float *w, const float *bias, float *out, int M, int N,
+                          int K, tgru_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return TGRU_E_DIMS;
+    if (!a || !w || !out) return TGRU_E_NULL;
+    GemmArgs g{};
+    g.A = a; g.lda = K; g.Bm = w; g.ldb = K; g.C = out; g.ldc = N; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.kchunk = K; g.slab_stride = 0; g.accumulate = 0;
+    g.amap = RowMap{0, 1, 1, nullptr};
+    g.bmap = g.amap;
+    g.cmap = g.amap;
+    TGRU_HIP(launch_gemm(g, true, true, 1, (hipStream_t)stream));
+    return TGRU_OK;
+}
+
+int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const int32_t *toff,
+                 const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+                 const float *const *b_hh, float *y, float *h_n, float *reserve, float *workspace,
+                 int B, int T, int In, int H, int L, int layout, tgru_stream_t stream) {
+    int rc = check_dims(B, T, In, H, L, layout);
+    if (rc != TGRU_OK) return rc;
+    if (!x || !y || !workspace || !w_ih || !w_hh || !b_ih || !b_hh) return TGRU_E_NULL;
+    if (layout == TGRU_LAYOUT_PACKED && (!lengths || !toff)) return TGRU_E_LAYOUT;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (reserve && !aligned16(reserve)) ||
+        (h_n && !aligned16(h_n)))
+        return TGRU_E_ALIGN;
+    for (int l = 0; l < L; ++l)
+        if (!w_ih[l] || !w_hh[l] || !b_ih[l] || !b_hh[l]) return TGRU_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const Dims d{B, T, In, H, L, layout};
+    float *gi = workspace;
+    float *wp = gi + align64(d.TB() * 3 * H);
+    float *pp = wp + align64(packed_whh_floats(H));
+
+    const float *in = x;
+    for (int l = 0; l < L; ++l) {
+        const int In_l = l == 0 ? In : H;
+        const bool top = l == L - 1;
+        GemmArgs g{};
+        g.A = in; g.lda = In_l; g.Bm = w_ih[l]; g.ldb = In_l; g.C = gi; g.ldc = 3 * H; g.bias = b_ih[l];
+        g.M = (int)d.TB(); g.N = 3 * H; g.K = In_l; g.kchunk = In_l; g.slab_stride = 0; g.accumulate = 0;
+        g.amap = l == 0 ? ext_map(d, toff) : id_map(d);
+        g.bmap = id_map(d);
+        g.cmap = id_map(d);
+        TGRU_HIP(launch_gemm(g, true, true, 1, s));
+        TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
+
+        FwdArgs f{};
+        f.gi = gi; f.wp = wp; f.b_hh = b_hh[l];
+        f.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
+        const bool need_int = !top || layout != TGRU_LAYOUT_TBF;
+        f.y_int = nullptr;
+        if (need_int) f.y_int = reserve ? reserve_y(d, reserve, l) : pp + (size_t)(l & 1) * align64(d.TBH());
+        if (top && !reserve) f.y_int = nullptr;   // inference: nobody reads the top layer's copy
+        f.y_ext = top ? y : nullptr;
+        f.ymap = ext_map(d, toff);
+        f.gates = reserve ? reserve_gates(d, reserve, l) : nullptr;
+        f.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
+        f.lengths = lengths;
+        f.B = B; f.T = T; f.H = H;
+        TGRU_HIP(launch_gru_fwd(f, s));
+        in = f.y_int;
+    }
+    return TGRU_OK;
+}
+
+int tgru_backward(const float *dy, const float *dh_n, const float *x, const float *h0, const float *y,
+                  const int32_t *lengths, const int32_t *toff, const float *const *w_ih,
+                  const float *const *w_hh, const float *const *b_ih, const float *const *b_hh,
+                  const float *reserve, float *workspace, float *dx, float *dh0, float *const *dw_ih,
+                  float *const *dw_hh, float *const *db_ih, float *const *db_hh, int B, int T, int In,
+                  int H, int L, int layout, int accumulate, tgru_stream_t stream) {
+    (void)b_ih; (void)b_hh;
+    int rc = check_dims(B, T, In, H, L, layout);
+    if (rc != TGRU_OK) return rc;
+    if (!x || !y || !reserve || !workspace || !w_ih || !w_hh || !dw_ih || !dw_hh || !db_ih || !db_hh)
+        return TGRU_E_NULL;
+    if (layout == TGRU_LAYOUT_PACKED && (!lengths || !toff)) return TGRU_E_LAYOUT;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || !aligned16(reserve) ||
+        (dy && !aligned16(dy)) || (dx && !aligned16(dx)))
+        return TGRU_E_ALIGN;
+    for (int l = 0; l < L; ++l)
+        if (!w_ih[l] || !w_hh[l] || !dw_ih[l] || !dw_hh[l] || !db_ih[l] || !db_hh[l]) return TGRU_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const Dims d{B, T, In, H, L, layout};
+    const BwdWs w = bwd_ws(d);
+    float *dg = workspace + w.dg;
+    float *wtp = workspace + w.wtp;
+    float *dbp = workspace + w.dbp;
+    float *slabs = workspace + w.slabs;
+    const size_t dyb_stride = align64(d.TB() * (size_t)(H > In ? H : In));
+    float *res = const_cast<float *>(reserve);
+    const int nblk = gru_batch_blocks(B);
+    const int TB = (int)d.TB();
+
+    for (int l = L - 1; l >= 0; --l) {
+        const int In_l = l == 0 ? In : H;
+        const bool top = l == L - 1;
+        const float *y_l = (top && layout == TGRU_LAYOUT_TBF) ? y : reserve_y(d, res, l);
+        const float *in = l == 0 ? x : reserve_y(d, res, l - 1);
+        TGRU_HIP(launch_pack_whh(w_hh[l], nullptr, wtp, H, s));
+
+        BwdArgs b{};
+        b.dy_int = top ? nullptr : workspace + w.dyb + (size_t)((l + 1) & 1) * dyb_stride;
+        b.dy_ext = top ? dy : nullptr;
+        b.dymap = ext_map(d, toff);
+        b.dh_n = dh_n ? dh_n + (size_t)l * B * H : nullptr;
+        b.wtp = wtp; b.y_int = y_l;
+        b.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
+        b.gates = reserve_gates(d, res, l);
+        b.dg = dg;
+        b.dh0 = dh0 ? dh0 + (size_t)l * B * H : nullptr;
+        b.db_part = dbp;
+        b.lengths = lengths;
+        b.B = B; b.T = T; b.H = H;
+        TGRU_HIP(launch_gru_bwd(b, s));
+        TGRU_HIP(launch_bias_grad(dbp, nblk, H, db_ih[l], db_hh[l], accumulate, s));
+
+        // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
+        {
+            int kc;
+            const int ns = split_for(3 * H, In_l, TB, &kc);
+            GemmArgs g{};
+            g.A = dg; g.lda = 4 * H; g.Bm = in; g.ldb = In_l; g.C = slabs; g.ldc = In_l; g.bias = nullptr;
+            g.M = 3 * H; g.N = In_l; g.K = TB; g.kchunk = kc; g.slab_stride = (long)3 * H * In_l;
+            g.accumulate = 0;
+            g.amap = id_map(d); g.cmap = id_map(d);
+            g.bmap = l == 0 ? ext_map(d, toff) : id_map(d);
+            TGRU_HIP(launch_gemm(g, false, false, ns, s));
+            TGRU_HIP(launch_slab_reduce(slabs, g.slab_stride, ns, dw_ih[l], (long)3 * H * In_l, accumulate, s));
+        }
+        // dW_hh = dgh^T . h_prev : dg rows of step t pair with this layer's output rows of step t-1
+        {
+            int kc;
+            const int K = TB - B;
+            const int ns = split_for(3 * H, H, K > 0 ? K : 1, &kc);
+            GemmArgs g{};
+            g.lda = 4 * H; g.Bm = y_l; g.ldb = H; g.ldc = H; g.bias = nullptr;
+            g.N = H; g.K = K; g.kchunk = kc; g.slab_stride = (long)3 * H * H; g.accumulate = 0;
+            g.amap = id_map(d); g.bmap = id_map(d); g.cmap = id_map(d);
+            g.A = dg + (size_t)B * 4 * H; g.M = 2 * H; g.C = slabs;                 // r, z rows
+            TGRU_HIP(launch_gemm(g, false, false, ns, s));
+            g.A = dg + (size_t)B * 4 * H + 3 * H; g.M = H; g.C = slabs + (size_t)2 * H * H;   // n rows: da_n * r
+            TGRU_HIP(launch_gemm(g, false, false, ns, s));
+            TGRU_HIP(launch_slab_reduce(slabs, g.slab_stride, ns, dw_hh[l], (long)3 * H * H, accumulate, s));
+            if (h0) {   // step 0 pairs with the initial state
+                g.Bm = h0 + (size_t)l * B * H; g.K = B; g.kchunk = (B + 15) / 16 * 16; g.slab_stride = 0;
+                g.accumulate = 1;
+                g.A = dg; g.M = 2 * H; g.C = dw_hh[l];
+                TGRU_HIP(launch_gemm(g, false, false, 1, s));
+                g.A = dg + 3 * H; g.M = H; g.C = dw_hh[l] + (size_t)2 * H * H;
+                TGRU_HIP(launch_gemm(g, false, false, 1, s));
+            }
+        }
+        // dX = dgi . W_ih  -> gradient of the layer below (or the caller's dx)
+        if (l > 0 || dx) {
+            GemmArgs g{};
+            g.A = dg; g.lda = 4 * H; g.Bm = w_ih[l]; g.ldb = In_l; g.bias = nullptr;
+            g.C = l == 0 ? dx : workspace + w.dyb + (size_t)(l & 1) * dyb_stride;
+            g.ldc = In_l; g.M = TB; g.N = In_l; g.K = 3 * H; g.kchunk = 3 * H; g.slab_stride = 0;
+            g.accumulate = 0;
+            g.amap = id_map(d); g.bmap = id_map(d);
+            g.cmap = l == 0 ? ext_map(d, toff) : id_map(d);
+            TGRU_HIP(launch_gemm(g, true, false, 1, s));
+        }
+    }
+    return TGRU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Internal declarations shared by the tgru HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgru {
+
+// ----------------------------------------------------------------------------------------------
+// Row addressing.  Inside the library every per-(b,t) buffer is time-major: row = t*B + b.
+// A RowMap turns such an internal row into the row of a caller tensor in its layout, or -1
+// when that (b,t) has no row (a packed sequence that has already ended).
+// ----------------------------------------------------------------------------------------------
+struct RowMap {
+    int mode;          // 0 identity (T,B,F), 1 batch-major (B,T,F), 2 packed rows
+    int B, T;
+    const int *toff;   // packed only: int32[T+1] prefix sum of batch sizes
+};
+
+__device__ __forceinline__ long map_row(const RowMap &rm, int m) {
+    if (rm.mode == 0) return m;
+    const int t = m / rm.B;
+    const int b = m - t * rm.B;
+    if (rm.mode == 1) return (long)b * rm.T + t;
+    const int o = rm.toff[t];
+    return (b < rm.toff[t + 1] - o) ? (long)(o + b) : -1L;
+}
+
+// ----------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM:  C(m,n) [+]= sum_k A(m,k) * B(k,n)  (+ bias[n])
+//   a_kc: A element (m,k) is at A[arow(m)*lda + k]  (k contiguous), else at A[k*lda + m]
+//   b_kc: B element (k,n) is at B[n*ldb + k]        (k contiguous), else at B[k*ldb + n]
+// split-K: gridDim.z slabs, slab z covers k in [z*kchunk, (z+1)*kchunk) and writes to
+// C + z*slab_stride (plain store); the caller reduces the slabs.
+// ----------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float *A; long lda;
+    const float *Bm; long ldb;
+    float *C; long ldc;
+    const float *bias;
+    int M, N, K;
+    int kchunk; long slab_stride;
+    int accumulate;     // only without split-K: C += result
+    RowMap amap;        // rows of A (a_kc only)
+    RowMap bmap;        // rows of B (!b_kc only): reduction index k -> caller row
+    RowMap cmap;        // rows of C
+};
+
+hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s);
+
+// out[i] (=|+=) sum_z slabs[z*stride + i], i < n
+hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float *out, long n,
+                              int accumulate, hipStream_t s);
+
+// ----------------------------------------------------------------------------------------------
+// Recurrent kernels (one launch per layer).
+// ----------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float *gi;        // (T*B, 3H) input projection incl. b_ih, time-major
+    const float *wp;        // packed W_hh fragments, see pack_whh_kernel
+    const float *b_hh;      // (3H)
+    const float *h0;        // (B,H) or null
+    float *y_int;           // (T*B, H) time-major layer output
+    float *y_ext;           // top layer only: caller's y in its layout, or null
+    RowMap ymap;
+    float *gates;           // 4 planes (r,z,n,hn) of (T*B, H), or null (inference)
+    float *h_n;             // (B,H) or null
+    const int *lengths;     // int32[B] or null
+    int B, T, H;
+};
+hipError_t launch_gru_fwd(const FwdArgs &a, hipStream_t s);
+
+struct BwdArgs {
+    const float *dy_int;    // (T*B, H) time-major gradient of this layer's output, or null
+    const float *dy_ext;    // top layer: caller's dy in its layout, or null
+    RowMap dymap;
+    const float *dh_n;      // (B,H) or null
+    const float *wtp;       // packed W_hh^T fragments, see pack_whh_t_kernel
+    const float *y_int;     // (T*B, H) this layer's output (h_t), time-major
+    const float *h0;        // (B,H) or null
+    const float *gates;     // 4 planes (r,z,n,hn)
+    float *dg;              // (T*B, 4H): da_r | da_z | da_n | da_n*r
+    float *dh0;             // (B,H) or null
+    float *db_part;         // (nblocks, 4H) per-workgroup column sums of dg
+    const int *lengths;
+    int B, T, H;
+};
+hipError_t launch_gru_bwd(const BwdArgs &a, hipStream_t s);
+int gru_batch_blocks(int B);
+
+// Packed weight fragment sizes (floats) and pack launches.
+size_t packed_whh_floats(int H);
+hipError_t launch_pack_whh(const float *w_hh, float *wp, float *wtp, int H, hipStream_t s);
+
+// db_ih / db_hh from the per-workgroup partial sums.
+hipError_t launch_bias_grad(const float *db_part, int nblocks, int H, float *db_ih, float *db_hh,
+                            int accumulate, hipStream_t s);
+
+}  // namespace tgru

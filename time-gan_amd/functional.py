@@ -1,0 +1,211 @@
+"""Host side of the GRU operator: tensors -> pointers -> libtgru.so, wrapped for autograd.
+
+The operator replaces `_VF.gru(...)` as reached from nn.GRU.forward
+(torch/nn/modules/rnn.py:1427-1437), i.e. the call the reference makes at
+outdated_files/TimeGANv1.py:61,139,220,299,376.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.TgruError(
+            f"{what} is on {t.device}: the tgru GRU only runs on a gfx950 GPU and has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise _lib.TgruError(f"{what} must be float32, got {t.dtype}")
+
+
+def _split_weights(flat: Sequence[torch.Tensor], L: int):
+    assert len(flat) == 4 * L, "expected weight_ih, weight_hh, bias_ih, bias_hh per layer"
+    return flat[0::4], flat[1::4], flat[2::4], flat[3::4]
+
+
+def _dims(x: torch.Tensor, layout: int, B: int, T: int, weights: Sequence[torch.Tensor]):
+    L = len(weights) // 4
+    H = weights[1].shape[1]
+    In = weights[0].shape[1]
+    if layout == LAYOUT_TBF:
+        assert tuple(x.shape) == (T, B, In), f"x {tuple(x.shape)} is not (T,B,In)=({T},{B},{In})"
+    elif layout == LAYOUT_BTF:
+        assert tuple(x.shape) == (B, T, In), f"x {tuple(x.shape)} is not (B,T,In)=({B},{T},{In})"
+    else:
+        assert x.dim() == 2 and x.shape[1] == In, f"packed x {tuple(x.shape)} is not (rows,{In})"
+    return In, H, L
+
+
+class _GRUFunction(torch.autograd.Function):
+    """y, h_n = GRU(x, h0) with lengths; saves the library's reserve buffer for backward."""
+
+    @staticmethod
+    def forward(ctx, x, h0, lengths, toff, B, T, layout, *weights):
+        _require_gpu(x, "input")
+        In, H, L = _dims(x, layout, B, T, weights)
+        x = x.contiguous()
+        weights = tuple(w.contiguous() for w in weights)
+        for w in weights:
+            _require_gpu(w, "weight")
+        h0c = None if h0 is None else h0.contiguous()
+        w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad)
+        with torch.cuda.device(dev):
+            lb = lib()
+            y = torch.empty(x.shape[:-1] + (H,), device=dev, dtype=torch.float32)
+            if layout == LAYOUT_PACKED:
+                pass   # every packed row is an active step, all rows get written
+            h_n = torch.empty((L, B, H), device=dev, dtype=torch.float32)
+            ws = torch.empty(lb.tgru_forward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
+                             dtype=torch.float32)
+            reserve = None
+            if need_grad:
+                reserve = torch.empty(lb.tgru_reserve_bytes(B, T, In, H, L, layout) // 4, device=dev,
+                                      dtype=torch.float32)
+            rc = lb.tgru_forward(_ptr(x), _ptr(h0c), _ptr(lengths), _ptr(toff),
+                                 _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
+                                 _ptr(y), _ptr(h_n), _ptr(reserve), _ptr(ws),
+                                 B, T, In, H, L, layout, _stream(dev))
+            check(rc, "tgru_forward")
+        ctx.dims = (B, T, In, H, L, layout)
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(x, h0c, y, lengths, toff, reserve, *weights)
+        return y, h_n
+
+    @staticmethod
+    def backward(ctx, dy, dh_n):
+        B, T, In, H, L, layout = ctx.dims
+        x, h0, y, lengths, toff, reserve, *weights = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
+        dev = x.device
+        dy = None if dy is None else dy.contiguous()
+        dh_n = None if dh_n is None else dh_n.contiguous()
+        with torch.cuda.device(dev):
+            lb = lib()
+            ws = torch.empty(lb.tgru_backward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
+                             dtype=torch.float32)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dh0 = torch.empty_like(h0) if (ctx.has_h0 and ctx.needs_input_grad[1]) else None
+            grads = [torch.empty_like(w) for w in weights]
+            gw_ih, gw_hh, gb_ih, gb_hh = _split_weights(grads, L)
+            rc = lb.tgru_backward(_ptr(dy), _ptr(dh_n), _ptr(x), _ptr(h0), _ptr(y),
+                                  _ptr(lengths), _ptr(toff),
+                                  _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
+                                  _ptr(reserve), _ptr(ws), _ptr(dx), _ptr(dh0),
+                                  _ptr_array(gw_ih), _ptr_array(gw_hh), _ptr_array(gb_ih), _ptr_array(gb_hh),
+                                  B, T, In, H, L, layout, 0, _stream(dev))
+            check(rc, "tgru_backward")
+        return (dx, dh0, None, None, None, None, None, *grads)
+
+
+def gru_apply(x: torch.Tensor, weights: Sequence[torch.Tensor], B: int, T: int, layout: int,
+              h0: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
+              toff: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Differentiable multi-layer GRU.
+
+    x in `layout` ((T,B,In), (B,T,In) or packed rows); weights flat in torch's order
+    [weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, weight_ih_l1, ...];
+    lengths / toff: int32 device tensors (see include/tgru.h), None for full-length sequences.
+    Returns (y in the same layout, h_n (L,B,H)).
+    """
+    return _GRUFunction.apply(x, h0, lengths, toff, B, T, layout, *weights)
+
+
+def gru_forward_backward_raw(x, weights, B, T, layout, dy, h0=None, dh_n=None, lengths=None, toff=None,
+                             want_dx=True):
+    """One forward + backward straight through the C ABI (no autograd graph); for benchmarks and tests.
+
+    Returns dict(y, h_n, dx, grads).
+    """
+    _require_gpu(x, "input")
+    In, H, L = _dims(x, layout, B, T, weights)
+    w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
+    dev = x.device
+    with torch.cuda.device(dev):
+        lb = lib()
+        y = torch.empty(x.shape[:-1] + (H,), device=dev, dtype=torch.float32)
+        h_n = torch.empty((L, B, H), device=dev, dtype=torch.float32)
+        ws = torch.empty(max(lb.tgru_forward_workspace_bytes(B, T, In, H, L),
+                             lb.tgru_backward_workspace_bytes(B, T, In, H, L)) // 4, device=dev,
+                         dtype=torch.float32)
+        reserve = torch.empty(lb.tgru_reserve_bytes(B, T, In, H, L, layout) // 4, device=dev,
+                              dtype=torch.float32)
+        s = _stream(dev)
+        check(lb.tgru_forward(_ptr(x), _ptr(h0), _ptr(lengths), _ptr(toff),
+                              _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
+                              _ptr(y), _ptr(h_n), _ptr(reserve), _ptr(ws),
+                              B, T, In, H, L, layout, s), "tgru_forward")
+        dx = torch.empty_like(x) if want_dx else None
+        dh0 = torch.empty_like(h0) if h0 is not None else None
+        grads = [torch.empty_like(w) for w in weights]
+        gw_ih, gw_hh, gb_ih, gb_hh = _split_weights(grads, L)
+        check(lb.tgru_backward(_ptr(dy), _ptr(dh_n), _ptr(x), _ptr(h0), _ptr(y), _ptr(lengths), _ptr(toff),
+                               _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
+                               _ptr(reserve), _ptr(ws), _ptr(dx), _ptr(dh0),
+                               _ptr_array(gw_ih), _ptr_array(gw_hh), _ptr_array(gb_ih), _ptr_array(gb_hh),
+                               B, T, In, H, L, layout, 0, s), "tgru_backward")
+    return {"y": y, "h_n": h_n, "dx": dx, "dh0": dh0, "grads": grads}
+
+
+def input_projection(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a @ w.T + bias through the library's fp32 MFMA GEMM (no autograd)."""
+    _require_gpu(a, "a")
+    _require_gpu(w, "w")
+    a = a.contiguous()
+    w = w.contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        check(lib().tgru_input_projection(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K,
+                                          _stream(a.device)), "tgru_input_projection")
+    return out
+
+
+def lengths_to_device(lengths, B: int, T: int, device) -> Optional[torch.Tensor]:
+    """Validate `lengths` the way pack_padded_sequence(enforce_sorted=True) does and move to device.
+
+    Returns None when every sequence has length T (the kernels' uniform fast path).
+    """
+    if lengths is None:
+        return None
+    if isinstance(lengths, torch.Tensor):
+        lens = lengths.detach().to("cpu").to(torch.int64).tolist()
+    else:
+        lens = [int(v) for v in lengths]
+    if len(lens) != B:
+        raise RuntimeError(f"Expected `len(lengths)` to be equal to batch_size, but got {len(lens)} "
+                           f"(batch_size={B})")
+    if min(lens) <= 0:
+        raise RuntimeError("Length of all samples has to be greater than 0, but found an element in "
+                           "'lengths' that is <= 0")
+    if any(lens[i] < lens[i + 1] for i in range(B - 1)):
+        raise RuntimeError("`lengths` array must be sorted in decreasing order when "
+                           "`enforce_sorted` is True. You can pass `enforce_sorted=False` to "
+                           "pack_padded_sequence and/or pad_packed_sequence to sidestep this requirement "
+                           "if you do not need ONNX exportability.")
+    if max(lens) > T:
+        raise RuntimeError(f"a length ({max(lens)}) exceeds the sequence dimension ({T})")
+    if min(lens) == T:
+        return None
+    return torch.tensor(lens, dtype=torch.int32, device=device)
