@@ -1,0 +1,202 @@
+"""Benchmark of the GRU forward + BPTT hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4] [--no-cpu]
+
+A step is one forward + full backward (dx and all weight gradients) of one 3-layer GRU stack over one
+batch of synthetic input already resident in HBM, issued through the C ABI (libtgru.so).  With N > 1
+every rank owns a batch shard of the same size (weak scaling) and the step ends with one RCCL
+all-reduce of the flat weight-gradient bucket, as data-parallel training needs.
+
+Rank 0 prints ONE JSON line.  `value` is sequences/s over all ranks.  `roofline` prices the whole
+step (all kernels of forward + backward, timed with HIP events on the launch stream) against the
+bound of the workload: HBM bytes for H=24, fp32 MFMA FLOPs for H>=96.  `cpu_baseline` times the
+operator the reference itself calls (torch.nn.GRU on CPU behind pack_padded_sequence) on the host
+cores of the same box, on a bounded number of steps of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (per-GPU batch, T, In(=H on the TimeGAN path), H, L, description)
+    "c2": (128, 24, 24, 24, 3, "stock config: GRU stack fwd+bwd, B128 T24 H24 L3 (6 features -> H by the module MLP)"),
+    "c3": (1024, 24, 96, 96, 3, "energy config: GRU stack fwd+bwd, B1024 T24 H96 L3"),
+    "c4": (2048, 256, 512, 512, 3, "stress config: GRU stack fwd+bwd, per-GPU shard B2048 T256 H512 L3"),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
+
+
+def algorithmic_work(B, T, In, H, L):
+    """FLOPs and bytes of one stack forward+backward (elementwise work excluded)."""
+    flops = 0.0
+    bytes_ = 0.0
+    for l in range(L):
+        in_l = In if l == 0 else H
+        flops += B * T * (18.0 * H * in_l + 18.0 * H * H)          # fwd 6+6, bwd 12+12 per (in,H) pair
+        bytes_ += B * T * 4.0 * (6 * H + 4 * in_l + 4 * H)           # fwd: x, y, 4 saved; bwd: dy, x, h, 4 saved, dx
+        bytes_ += 12.0 * (3 * H * in_l + 3 * H * H + 6 * H)          # weights: read fwd, read bwd, write grads
+    return flops, bytes_
+
+
+def make_weights(In, H, L, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    k = 1.0 / (H ** 0.5)
+    ws = []
+    for l in range(L):
+        in_l = In if l == 0 else H
+        for shape in ((3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)):
+            ws.append(((torch.rand(shape, generator=g) * 2 - 1) * k).to(device))
+    return ws
+
+
+def cpu_baseline(B, T, In, H, L, budget_s=20.0):
+    """torch.nn.GRU CPU fwd+bwd through pack/pad, as the reference calls it."""
+    import torch.nn as nn
+    results = []
+    for threads in (1, min(16, os.cpu_count() or 1)):
+        torch.set_num_threads(threads)
+        torch.manual_seed(42)
+        gru = nn.GRU(In, H, L, batch_first=True)
+        Bc = B if B * T * H <= 1024 * 24 * 96 else 256     # bounded sample for the stress shape
+        x = torch.rand(Bc, T, In, requires_grad=True)
+        lens = [T] * Bc
+
+        def step():
+            gru.zero_grad()
+            p = nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=True)
+            o, _ = gru(p)
+            y, _ = nn.utils.rnn.pad_packed_sequence(o, batch_first=True, padding_value=0, total_length=T)
+            y.sum().backward()
+        step()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 200:
+                break
+        results.append({"threads": threads, "seqs_per_s": Bc * n / el, "steps": n, "batch": Bc})
+        if threads == (os.cpu_count() or 1):
+            break
+    best = max(results, key=lambda r: r["seqs_per_s"])
+    return {"value": round(best["seqs_per_s"], 2), "unit": "seqs/s", "cores": best["threads"],
+            "kind": "reference",
+            "sample": (f"torch {torch.__version__} CPU nn.GRU (the operator the reference calls) behind "
+                       f"pack_padded_sequence/pad_packed_sequence, fwd+bwd, batch {best['batch']} x {best['steps']} "
+                       f"steps of the same T/H/L; all thread counts tried: "
+                       + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}" for r in results))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-allreduce", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import timegan_amd as tg
+
+    B, T, In, H, L, desc = WORKLOADS[args.workload]
+    torch.manual_seed(42 + rank)
+    weights = make_weights(In, H, L, dev, seed=42)           # replicated parameters
+    x = torch.rand(T, B, In, device=dev)                      # U[0,1) like MinMax-scaled data
+    dy = torch.randn(T, B, H, device=dev)
+    runner = tg.GRURunner(B, T, In, H, L, tg.LAYOUT_TBF, dev)
+    runner.set_weights(weights)
+    do_ar = world > 1 and not args.no_allreduce
+
+    def step():
+        runner.forward(x)
+        runner.backward(dy)
+        if do_ar:
+            dist.all_reduce(runner.flat_grads)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        runner.forward(x)
+        runner.backward(dy)
+        ev1[i].record()
+        if do_ar:
+            dist.all_reduce(runner.flat_grads)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    dev_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+
+    if rank == 0:
+        flops, bytes_ = algorithmic_work(B, T, In, H, L)
+        value = world * B * args.steps / elapsed
+        if H < 64:
+            achieved = bytes_ / (dev_ms_avg * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None}
+        else:
+            achieved = flops / (dev_ms_avg * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None}
+        roof["kernel"] = "whole step: every kernel of one stack forward+backward (HIP events around the step)"
+        roof["device_ms_per_step"] = round(dev_ms_avg, 4)
+        roof["device_ms_median"] = round(dev_ms[len(dev_ms) // 2], 4)
+        roof["algorithmic_bytes_per_step"] = bytes_
+        roof["algorithmic_flops_per_step"] = flops
+        out = {
+            "metric": "GRU stack fwd+bwd sequences/sec",
+            "value": round(value, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "global_batch": world * B, "seq_len": T,
+                       "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

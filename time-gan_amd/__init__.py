@@ -1,4 +1,4 @@
 """MI355X-native GRU forward / BPTT behind the torch.nn.GRU interface, for TimeGAN's modules."""
 from ._lib import TgruError, lib, LAYOUT_TBF, LAYOUT_BTF, LAYOUT_PACKED  # noqa: F401
-from .functional import gru_forward_backward_raw, gru_apply, input_projection  # noqa: F401
+from .functional import GRURunner, gru_forward_backward_raw, gru_apply, input_projection  # noqa: F401
 from .gru import GRU  # noqa: F401

@@ -209,3 +209,61 @@ def lengths_to_device(lengths, B: int, T: int, device) -> Optional[torch.Tensor]
     if min(lens) == T:
         return None
     return torch.tensor(lens, dtype=torch.int32, device=device)
+
+
+class GRURunner:
+    """Pre-allocated buffers + direct C-ABI calls for one fixed problem shape.
+
+    No allocation and no autograd bookkeeping per step: `forward()` then `backward(dy)` issue only
+    the library's kernel launches on the current stream.  All parameter gradients live in one flat
+    buffer (`flat_grads`) so a data-parallel caller can all-reduce them with one collective.
+    """
+
+    def __init__(self, B: int, T: int, In: int, H: int, L: int, layout: int, device, want_dx: bool = True):
+        self.dims = (B, T, In, H, L, layout)
+        self.device = torch.device(device)
+        lb = lib()
+        f32 = dict(device=self.device, dtype=torch.float32)
+        shape = {LAYOUT_TBF: (T, B), LAYOUT_BTF: (B, T)}[layout]
+        self.y = torch.empty(shape + (H,), **f32)
+        self.h_n = torch.empty((L, B, H), **f32)
+        self.dx = torch.empty(shape + (In,), **f32) if want_dx else None
+        self.ws = torch.empty(max(lb.tgru_forward_workspace_bytes(B, T, In, H, L),
+                                  lb.tgru_backward_workspace_bytes(B, T, In, H, L)) // 4, **f32)
+        self.reserve = torch.empty(lb.tgru_reserve_bytes(B, T, In, H, L, layout) // 4, **f32)
+        shapes = []
+        for l in range(L):
+            in_l = In if l == 0 else H
+            shapes += [(3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)]
+        # keep every gradient 16-byte aligned inside the flat buffer
+        offs, n = [], 0
+        for s in shapes:
+            offs.append(n)
+            n += (int(torch.Size(s).numel()) + 3) // 4 * 4
+        self.flat_grads = torch.zeros(n, **f32)
+        self.grads = [self.flat_grads[o:o + torch.Size(s).numel()].view(s) for o, s in zip(offs, shapes)]
+        self._gptr = [_ptr_array(g) for g in _split_weights(self.grads, L)]
+        self.weights = None
+        self._wptr = None
+
+    def set_weights(self, weights: Sequence[torch.Tensor]):
+        L = self.dims[4]
+        self.weights = [w.contiguous() for w in weights]
+        self._wptr = [_ptr_array(w) for w in _split_weights(self.weights, L)]
+
+    def forward(self, x: torch.Tensor, lengths=None):
+        B, T, In, H, L, layout = self.dims
+        self.x = x
+        self.lengths = lengths
+        check(lib().tgru_forward(_ptr(x), None, _ptr(lengths), None, *self._wptr,
+                                 _ptr(self.y), _ptr(self.h_n), _ptr(self.reserve), _ptr(self.ws),
+                                 B, T, In, H, L, layout, _stream(self.device)), "tgru_forward")
+        return self.y
+
+    def backward(self, dy: torch.Tensor):
+        B, T, In, H, L, layout = self.dims
+        check(lib().tgru_backward(_ptr(dy), None, _ptr(self.x), None, _ptr(self.y), _ptr(self.lengths), None,
+                                  *self._wptr, _ptr(self.reserve), _ptr(self.ws), _ptr(self.dx), None,
+                                  *self._gptr, B, T, In, H, L, layout, 0, _stream(self.device)),
+              "tgru_backward")
+        return self.dx
