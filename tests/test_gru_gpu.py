@@ -89,9 +89,19 @@ def _compare(res, ref, tag):
             assert_close(a, b, GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} {name}_l{l}")
 
 
+@pytest.fixture(params=["auto", "per_layer"])
+def kernel_path(request, monkeypatch):
+    """auto: whole-stack kernels when the shape allows; per_layer: force the per-layer kernels."""
+    if request.param == "per_layer":
+        monkeypatch.setenv("TGRU_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("TGRU_FORCE_GENERIC", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("layout", ["tbf", "btf", "packed"])
 @pytest.mark.parametrize("name", gru_case_names())
-def test_golden_fixture(name, layout):
+def test_golden_fixture(name, layout, kernel_path):
     case = load_gru_case(name)
     res = _run(case, layout)
     _compare(res, expected(case, "f32"), f"{name}[{layout}] vs torch-cpu fp32")

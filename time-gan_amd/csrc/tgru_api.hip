@@ -1,6 +1,7 @@
 // C ABI of the tgru library: argument checks, buffer carving and the per-layer launch sequence.
 #include "../../include/tgru.h"
 #include "tgru_internal.h"
+#include <stdlib.h>
 
 using namespace tgru;
 
@@ -26,6 +27,14 @@ int check_dims(int B, int T, int In, int H, int L, int layout) {
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Small stacks run as whole-stack kernels (gru_small.hip).  TGRU_FORCE_GENERIC=1 in the
+// environment selects the per-layer kernels instead (used by the tests to cover both paths).
+bool use_small(int In, int H, int L) {
+    if (H > kSmallMaxH || In > kSmallMaxIn || L > kSmallMaxL) return false;
+    const char *e = getenv("TGRU_FORCE_GENERIC");
+    return !(e && e[0] == '1');
+}
 
 // reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
 size_t reserve_floats(const Dims &d) {
@@ -66,10 +75,12 @@ struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, total; int max_slabs; };
 BwdWs bwd_ws(const Dims &d) {
     BwdWs w;
     size_t off = 0;
-    w.dg = off; off += align64(d.TB() * 4 * d.H);
+    // the whole-stack path keeps one dg buffer per layer (sized for it regardless of the env switch)
+    const bool small_shape = d.H <= kSmallMaxH && d.In <= kSmallMaxIn && d.L <= kSmallMaxL;
+    w.dg = off; off += (small_shape ? (size_t)d.L : 1) * align64(d.TB() * 4 * d.H);
     w.dyb = off; off += 2 * align64(d.TB() * (size_t)(d.H > d.In ? d.H : d.In));
     w.wtp = off; off += align64(packed_whh_floats(d.H));
-    w.dbp = off; off += align64((size_t)gru_batch_blocks(d.B) * 4 * d.H);
+    w.dbp = off; off += align64((size_t)gru_batch_blocks(d.B) * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
     int ns = split_for(3 * d.H, widest, (long)d.TB(), &kc);
@@ -168,6 +179,22 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
     float *wp = gi + align64(d.TB() * 3 * H);
     float *pp = wp + align64(packed_whh_floats(H));
 
+    if (use_small(In, H, L)) {
+        SmallFwdArgs f{};
+        f.x = x; f.xmap = ext_map(d, toff); f.In = In;
+        for (int l = 0; l < L; ++l) {
+            f.w_ih[l] = w_ih[l]; f.w_hh[l] = w_hh[l]; f.b_ih[l] = b_ih[l]; f.b_hh[l] = b_hh[l];
+            const bool top = l == L - 1;
+            const bool need_int = !top || layout != TGRU_LAYOUT_TBF;
+            f.y_int[l] = (reserve && need_int) ? reserve_y(d, reserve, l) : nullptr;
+            f.gates[l] = reserve ? reserve_gates(d, reserve, l) : nullptr;
+        }
+        f.h0 = h0; f.y_ext = y; f.ymap = ext_map(d, toff); f.h_n = h_n; f.lengths = lengths;
+        f.B = B; f.T = T; f.H = H; f.L = L;
+        TGRU_HIP(launch_gru_small_fwd(f, s));
+        return TGRU_OK;
+    }
+
     const float *in = x;
     for (int l = 0; l < L; ++l) {
         const int In_l = l == 0 ? In : H;
@@ -228,6 +255,29 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     float *res = const_cast<float *>(reserve);
     const int nblk = gru_batch_blocks(B);
     const int TB = (int)d.TB();
+
+    if (use_small(In, H, L)) {
+        SmallBwdArgs b{};
+        SmallWgradArgs g{};
+        const size_t dg_stride = align64(d.TB() * 4 * H);
+        for (int l = 0; l < L; ++l) {
+            const bool top = l == L - 1;
+            const float *y_l = (top && layout == TGRU_LAYOUT_TBF) ? y : reserve_y(d, res, l);
+            b.w_ih[l] = w_ih[l]; b.w_hh[l] = w_hh[l];
+            b.y_int[l] = y_l; b.gates[l] = reserve_gates(d, res, l);
+            b.dg[l] = dg + (size_t)l * dg_stride;
+            g.dg[l] = b.dg[l]; g.y_int[l] = y_l;
+            g.dw_ih[l] = dw_ih[l]; g.dw_hh[l] = dw_hh[l]; g.db_ih[l] = db_ih[l]; g.db_hh[l] = db_hh[l];
+        }
+        b.dy_ext = dy; b.dymap = ext_map(d, toff); b.dh_n = dh_n; b.h0 = h0;
+        b.dx_ext = dx; b.dxmap = ext_map(d, toff); b.In = In; b.dh0 = dh0; b.db_part = dbp;
+        b.lengths = lengths; b.B = B; b.T = T; b.H = H; b.L = L;
+        TGRU_HIP(launch_gru_small_bwd(b, s));
+        g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp; g.nblk = nblk;
+        g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
+        TGRU_HIP(launch_gru_small_wgrad(g, s));
+        return TGRU_OK;
+    }
 
     for (int l = L - 1; l >= 0; --l) {
         const int In_l = l == 0 ? In : H;

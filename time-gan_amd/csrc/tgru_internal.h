@@ -95,4 +95,51 @@ hipError_t launch_pack_whh(const float *w_hh, float *wp, float *wtp, int H, hipS
 hipError_t launch_bias_grad(const float *db_part, int nblocks, int H, float *db_ih, float *db_hh,
                             int accumulate, hipStream_t s);
 
+// ----------------------------------------------------------------------------------------------
+// Whole-stack kernels for small hidden sizes (gru_small.hip).
+// ----------------------------------------------------------------------------------------------
+constexpr int kSmallMaxH = 32;
+constexpr int kSmallMaxIn = 32;
+constexpr int kSmallMaxL = 8;
+
+struct SmallFwdArgs {
+    const float *x; RowMap xmap; int In;
+    const float *w_ih[kSmallMaxL], *w_hh[kSmallMaxL], *b_ih[kSmallMaxL], *b_hh[kSmallMaxL];
+    const float *h0;               // (L,B,H) or null
+    float *y_ext; RowMap ymap;     // caller's y
+    float *y_int[kSmallMaxL];      // per layer (T*B,H) time-major, or null
+    float *gates[kSmallMaxL];      // per layer 4 planes, or null
+    float *h_n;                    // (L,B,H) or null
+    const int *lengths;
+    int B, T, H, L;
+};
+hipError_t launch_gru_small_fwd(const SmallFwdArgs &a, hipStream_t s);
+
+struct SmallBwdArgs {
+    const float *dy_ext; RowMap dymap;
+    const float *dh_n;             // (L,B,H) or null
+    const float *w_ih[kSmallMaxL], *w_hh[kSmallMaxL];
+    const float *y_int[kSmallMaxL];
+    const float *gates[kSmallMaxL];
+    const float *h0;
+    float *dg[kSmallMaxL];         // per layer (T*B, 4H)
+    float *dx_ext; RowMap dxmap; int In;
+    float *dh0;                    // (L,B,H) or null
+    float *db_part;                // (nblk, L, 4H)
+    const int *lengths;
+    int B, T, H, L;
+};
+hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s);
+
+struct SmallWgradArgs {
+    const float *dg[kSmallMaxL];
+    const float *x; RowMap xmap; int In;
+    const float *y_int[kSmallMaxL];
+    const float *h0;
+    const float *db_part; int nblk;
+    float *dw_ih[kSmallMaxL], *dw_hh[kSmallMaxL], *db_ih[kSmallMaxL], *db_hh[kSmallMaxL];
+    int B, T, H, L, accumulate;
+};
+hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s);
+
 }  // namespace tgru
