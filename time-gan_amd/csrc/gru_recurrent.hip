@@ -20,7 +20,14 @@ namespace tgru {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+// see gru_small.hip: pads the MFMA-result hazard across control flow
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+
+__device__ __forceinline__ void lds_barrier() {
+    // one asm statement with a memory clobber: the compiler must not move LDS accesses across it
+    // (the s_barrier builtin alone is not a compiler-level memory barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __host__ __device__ inline int hidden_tiles(int H) { return (H + 15) / 16; }
 
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
             }
         }
 
+        mfma_drain();
         float *hnxt = lds_h + (cur ^ 1) * nHT * 256;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -177,9 +185,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float ghn = acc[i][2][c] + bh[i][2][c];
-                const float r = sigmoidf_(gi[i][0][c] + acc[i][0][c] + bh[i][0][c]);
-                const float z = sigmoidf_(gi[i][1][c] + acc[i][1][c] + bh[i][1][c]);
-                const float n = tanhf(gi[i][2][c] + r * ghn);
+                const float r = fast_sigmoid(gi[i][0][c] + acc[i][0][c] + bh[i][0][c]);
+                const float z = fast_sigmoid(gi[i][1][c] + acc[i][1][c] + bh[i][1][c]);
+                const float n = fast_tanh(gi[i][2][c] + r * ghn);
                 const float hnew = (1.f - z) * n + z * hreg[i][c];
                 rv[c] = r; zv[c] = z; nv[c] = n; hnv[c] = ghn;
                 if (active && j0 + c < H) hreg[i][c] = hnew;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 }
@@ -302,54 +310,81 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(BwdArgs a) {
     float dhc[TPW][4];        // gradient carried into h_t from step t+1
     float dbs[TPW][4][4];     // running column sums of dg for the bias gradients
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int tile = wave * TPW + i;
+    for (int i = 0; i < TPW; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int j = 16 * tile + 4 * gq + c;
-            // dh_n enters at each sequence's own last step; added below when t == len-1
-            dhc[i][c] = 0.f;
+            dhc[i][c] = 0.f;   // dh_n enters at each sequence's own last step, see load_in
 #pragma unroll
             for (int g = 0; g < 4; ++g) dbs[i][g][c] = 0.f;
-            (void)j;
         }
-    }
-    __syncthreads();
+
+    // everything the elementwise part of one step needs for one owned tile
+    struct StepIn { float4 r, z, n, hn, hp, dy; };
+    auto ld = [&](const float *p, int nv) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec) { if (nv > 0) v = *reinterpret_cast<const float4 *>(p); }
+        else {
+            if (nv > 0) v.x = p[0];
+            if (nv > 1) v.y = p[1];
+            if (nv > 2) v.z = p[2];
+            if (nv > 3) v.w = p[3];
+        }
+        return v;
+    };
+    auto load_in = [&](int t, int i, StepIn &s) {
+        s.r = s.z = s.n = s.hn = s.hp = s.dy = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tile = wave * TPW + i;
+        const int j0 = 16 * tile + 4 * gq;
+        const int jn = min(4, max(0, H - j0));
+        if (tile < nHT && t >= 0 && t < len && jn > 0) {
+            const long row = (long)t * B + bglob;
+            const float *gp = a.gates + row * H + j0;
+            s.r = ld(gp, jn); s.z = ld(gp + plane, jn); s.n = ld(gp + 2 * plane, jn); s.hn = ld(gp + 3 * plane, jn);
+            if (t > 0) s.hp = ld(a.y_int + (row - B) * H + j0, jn);
+            else if (a.h0) s.hp = ld(a.h0 + (long)bglob * H + j0, jn);
+            if (a.dy_int) s.dy = ld(a.dy_int + row * H + j0, jn);
+            if (a.dy_ext) {
+                const long er = map_tb(a.dymap, t, bglob);
+                if (er >= 0) { const float4 e = ld(a.dy_ext + er * H + j0, jn); s.dy.x += e.x; s.dy.y += e.y; s.dy.z += e.z; s.dy.w += e.w; }
+            }
+            if (a.dh_n && t == len - 1) {
+                const float4 e = ld(a.dh_n + (long)bglob * H + j0, jn);
+                s.dy.x += e.x; s.dy.y += e.y; s.dy.z += e.z; s.dy.w += e.w;
+            }
+        }
+    };
+    // with one tile per wave the step is short, so its inputs are loaded one step ahead
+    StepIn nxt;
+    if (TPW == 1) load_in(T - 1, 0, nxt);
+    lds_barrier();
 
     for (int t = T - 1; t >= 0; --t) {
         const bool active = t < len;
         const long row = (long)t * B + bglob;
-        long erow = -1;
-        if (a.dy_ext && active) erow = map_row(a.dymap, (int)row);
         float dz_keep[TPW][4];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int tile = wave * TPW + i;
             if (tile >= nHT) continue;
             const int j0 = 16 * tile + 4 * gq;
+            StepIn in;
+            if (TPW == 1) in = nxt; else load_in(t, i, in);
+            const float rr[4] = {in.r.x, in.r.y, in.r.z, in.r.w}, zz[4] = {in.z.x, in.z.y, in.z.z, in.z.w};
+            const float nn[4] = {in.n.x, in.n.y, in.n.z, in.n.w}, hh[4] = {in.hn.x, in.hn.y, in.hn.z, in.hn.w};
+            const float hq[4] = {in.hp.x, in.hp.y, in.hp.z, in.hp.w}, dyv[4] = {in.dy.x, in.dy.y, in.dy.z, in.dy.w};
             float dar[4], daz[4], dan[4], dgn[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int j = j0 + c;
-                float r = 0.f, z = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dy = 0.f;
-                if (active && j < H) {
-                    const float *gp = a.gates + row * H + j;
-                    r = gp[0]; z = gp[plane]; n = gp[2 * plane]; hn = gp[3 * plane];
-                    hp = (t > 0) ? a.y_int[(row - B) * H + j] : (a.h0 ? a.h0[(long)bglob * H + j] : 0.f);
-                    if (a.dy_int) dy = a.dy_int[row * H + j];
-                    if (erow >= 0) dy += a.dy_ext[erow * H + j];
-                    if (a.dh_n && t == len - 1) dy += a.dh_n[(long)bglob * H + j];
-                }
-                const float d = dy + dhc[i][c];
-                const float dn = d * (1.f - z);
-                const float dzz = d * (hp - n);
-                const float an = dn * (1.f - n * n);
-                dan[c] = an;
-                dar[c] = an * hn * r * (1.f - r);
-                daz[c] = dzz * z * (1.f - z);
-                dgn[c] = an * r;
-                dz_keep[i][c] = active ? d * z : dhc[i][c];
-                if (!(active && j < H)) { dan[c] = 0.f; dar[c] = 0.f; daz[c] = 0.f; dgn[c] = 0.f; }
+                const bool on = active && j0 + c < H;
+                const float d = on ? dyv[c] + dhc[i][c] : 0.f;
+                const float dn = d * (1.f - zz[c]);
+                const float dzz = d * (hq[c] - nn[c]);
+                const float an = dn * (1.f - nn[c] * nn[c]);
+                dan[c] = on ? an : 0.f;
+                dar[c] = on ? an * hh[c] * rr[c] * (1.f - rr[c]) : 0.f;
+                daz[c] = on ? dzz * zz[c] * (1.f - zz[c]) : 0.f;
+                dgn[c] = on ? an * rr[c] : 0.f;
+                dz_keep[i][c] = active ? d * zz[c] : dhc[i][c];
                 dbs[i][0][c] += dar[c]; dbs[i][1][c] += daz[c]; dbs[i][2][c] += dan[c]; dbs[i][3][c] += dgn[c];
             }
             // fragments for the W_hh^T product: k-block (gate, tile)
@@ -372,7 +407,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(BwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        if (TPW == 1) load_in(t - 1, 0, nxt);
+        lds_barrier();
 
         // dh_{t-1} += W_hh^T . dgh_t  (two accumulator chains per tile to cover MFMA latency)
         f32x4 acc[TPW][2];
@@ -393,11 +429,12 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(BwdArgs a) {
                 }
             }
         }
+        mfma_drain();
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) dhc[i][c] = dz_keep[i][c] + (active ? acc[i][0][c] + acc[i][1][c] : 0.f);
-        __syncthreads();
+        lds_barrier();
     }
 
     // dh0 and the per-workgroup bias partial sums (sum over the 16 sequences of this workgroup)

@@ -10,7 +10,10 @@
 //     state and the layer-to-layer activations move between waves as MFMA B fragments through
 //     LDS (the D fragment of a hidden tile is the B fragment of the matching k-block, so one
 //     lane-linear 16-byte store / load per lane, no transposition);
-//   * the input projection of every layer is fused into the step (no gi buffer at all).
+//   * the input projection of every layer is fused into the step (no gi buffer at all);
+//   * every global load / store of a tick is issued at the top of the tick (results of the
+//     previous tick are stored one tick late, inputs of the next tick are loaded one tick early),
+//     so memory latency hides behind the tick's MFMA chain instead of adding to it.
 //
 // The backward kernel mirrors this in reverse time / reverse layer order and also produces dx;
 // gru_small_wgrad_kernel then turns the dg buffers into all weight and bias gradients of all
@@ -21,43 +24,55 @@ namespace tgru {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigm_(float v) { return 1.f / (1.f + expf(-v)); }
-
 __device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // one asm statement with a memory clobber: the compiler must not move LDS accesses across it
+    // (the s_barrier builtin alone is not a compiler-level memory barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// 4 consecutive floats p[0..3], element c valid iff c < nvalid; vector load when possible
-__device__ __forceinline__ float4 load4(const float *p, int nvalid, bool vec_ok) {
+// 4 consecutive floats p[0..3], element c valid iff c < nvalid.  VEC: nvalid is 0 or >= 4 and p
+// is 16-byte aligned, so the access is one dwordx4; otherwise element-wise with guards.
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float *p, int nvalid) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const float4 *>(p);
-    if (nvalid > 0) v.x = p[0];
-    if (nvalid > 1) v.y = p[1];
-    if (nvalid > 2) v.z = p[2];
-    if (nvalid > 3) v.w = p[3];
+    if (VEC) {
+        if (nvalid > 0) v = *reinterpret_cast<const float4 *>(p);
+    } else {
+        if (nvalid > 0) v.x = p[0];
+        if (nvalid > 1) v.y = p[1];
+        if (nvalid > 2) v.z = p[2];
+        if (nvalid > 3) v.w = p[3];
+    }
     return v;
 }
-__device__ __forceinline__ void store4(float *p, float4 v, int nvalid, bool vec_ok) {
-    if (nvalid >= 4 && vec_ok) { *reinterpret_cast<float4 *>(p) = v; return; }
-    if (nvalid > 0) p[0] = v.x;
-    if (nvalid > 1) p[1] = v.y;
-    if (nvalid > 2) p[2] = v.z;
-    if (nvalid > 3) p[3] = v.w;
+template <bool VEC>
+__device__ __forceinline__ void st4(float *p, float4 v, int nvalid) {
+    if (VEC) {
+        if (nvalid > 0) *reinterpret_cast<float4 *>(p) = v;
+    } else {
+        if (nvalid > 0) p[0] = v.x;
+        if (nvalid > 1) p[1] = v.y;
+        if (nvalid > 2) p[2] = v.z;
+        if (nvalid > 3) p[3] = v.w;
+    }
 }
 
-#define MFMA4(acc, A, Bf)                                                          \
-    do {                                                                           \
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (Bf).x, acc, 0, 0, 0);   \
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (Bf).y, acc, 0, 0, 0);   \
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (Bf).z, acc, 0, 0, 0);   \
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (Bf).w, acc, 0, 0, 0);   \
-    } while (0)
+// Wait states between the last MFMA of a block and the first VALU read of its result.  hipcc pads
+// this hazard inside a basic block, but a reader that is reached through a branch taken right
+// after the MFMA was observed to get the upper result registers before they were written, so
+// every MFMA block that is followed by control flow ends with this.
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 mf(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#define F4ARR(name, v) const float name[4] = {(v).x, (v).y, (v).z, (v).w}
 
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
-template <int NT, int MAXT>
+template <int NT, int MAXT, bool VEC>
 __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // hbuf[2][L][NT][256]
     const int H = a.H, B = a.B, T = a.T, L = a.L;
@@ -70,10 +85,10 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
     const int len = bvalid ? (a.lengths ? a.lengths[bglob] : T) : 0;
     const int In_l = (l == 0) ? a.In : H;
     const int nQin = (In_l + 15) / 16;
-    const bool hvec = (H & 3) == 0;
-    const bool ivec = (In_l & 3) == 0;
     const int j0 = 16 * tile + 4 * gq;            // first hidden unit of this lane
     const int jn = min(4, max(0, H - j0));        // how many of its 4 units exist
+    const float *wi = a.w_ih[l], *wh = a.w_hh[l], *bi = a.b_ih[l], *bhp = a.b_hh[l];
+    float *yint = a.y_int[l], *gates = a.gates[l];
 
     // weight fragments: lane (i = lane&15, gq) holds W[g*H + 16*tile + i][16*q + 4*gq + c]
     float4 wih[3][2], whh[3][NT];
@@ -84,27 +99,27 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c0 = 16 * q + 4 * gq;
-                wih[g][q] = (r < H && q < nQin)
-                                ? load4(a.w_ih[l] + (long)(g * H + r) * In_l + c0, In_l - c0, ivec)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                wih[g][q] = ld4<VEC>(wi + (long)(g * H + r) * In_l + c0, (r < H && q < nQin) ? In_l - c0 : 0);
             }
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
                 const int c0 = 16 * q + 4 * gq;
-                whh[g][q] = (r < H) ? load4(a.w_hh[l] + (long)(g * H + r) * H + c0, H - c0, hvec)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                whh[g][q] = ld4<VEC>(wh + (long)(g * H + r) * H + c0, (r < H) ? H - c0 : 0);
             }
         }
     }
     float brz[2][4], bin[4], bhn[4], hreg[4];
+    {
+        const float4 i0 = ld4<VEC>(bi + j0, jn), i1 = ld4<VEC>(bi + H + j0, jn), i2 = ld4<VEC>(bi + 2 * H + j0, jn);
+        const float4 h0_ = ld4<VEC>(bhp + j0, jn), h1 = ld4<VEC>(bhp + H + j0, jn), h2 = ld4<VEC>(bhp + 2 * H + j0, jn);
+        const float4 hi = (a.h0 && bvalid) ? ld4<VEC>(a.h0 + ((long)l * B + bglob) * H + j0, jn)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        F4ARR(i0a, i0); F4ARR(i1a, i1); F4ARR(i2a, i2); F4ARR(h0a, h0_); F4ARR(h1a, h1); F4ARR(h2a, h2); F4ARR(hia, hi);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool ok = c < jn;
-        brz[0][c] = ok ? a.b_ih[l][j0 + c] + a.b_hh[l][j0 + c] : 0.f;
-        brz[1][c] = ok ? a.b_ih[l][H + j0 + c] + a.b_hh[l][H + j0 + c] : 0.f;
-        bin[c] = ok ? a.b_ih[l][2 * H + j0 + c] : 0.f;
-        bhn[c] = ok ? a.b_hh[l][2 * H + j0 + c] : 0.f;
-        hreg[c] = (ok && bvalid && a.h0) ? a.h0[((long)l * B + bglob) * H + j0 + c] : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            brz[0][c] = i0a[c] + h0a[c]; brz[1][c] = i1a[c] + h1a[c];
+            bin[c] = i2a[c]; bhn[c] = h2a[c]; hreg[c] = hia[c];
+        }
     }
     // both parities start from h0 so that step 0 of every layer reads its initial state
     {
@@ -118,30 +133,55 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
     // layer 0 reads x straight from global memory as B fragments, one step ahead
     float4 xn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     auto load_x = [&](int t) {
-        if (t < T && t < len) {
-            const long er = map_row(a.xmap, t * B + bglob);
+        if (t < len) {   // len <= T
+            const long er = map_tb(a.xmap, t, bglob);
             if (er >= 0) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int c0 = 16 * q + 4 * gq;
-                    if (q < nQin) xn[q] = load4(a.x + er * a.In + c0, a.In - c0, ivec && ((a.In & 3) == 0));
+                    if (q < nQin) xn[q] = ld4<VEC>(a.x + er * a.In + c0, a.In - c0);
                 }
             }
         }
     };
     if (l == 0) load_x(0);
 
+    // results of the previous tick, stored at the top of the next one
+    float4 py = xn[0], pr = xn[0], pz = xn[0], pn = xn[0], phn = xn[0];
+    int pt = 0;
+    bool pact = false, pend = false;
+    auto flush = [&]() {
+        if (bvalid && jn > 0) {
+            const long row = (long)pt * B + bglob;
+            if (yint) st4<VEC>(yint + row * H + j0, py, jn);
+            if (l == L - 1 && a.y_ext) {
+                const long er = map_tb(a.ymap, pt, bglob);
+                if (er >= 0) st4<VEC>(a.y_ext + er * H + j0, py, jn);
+            }
+            if (gates && pact) {
+                float *gp = gates + row * H + j0;
+                st4<VEC>(gp, pr, jn);
+                st4<VEC>(gp + plane, pz, jn);
+                st4<VEC>(gp + 2 * plane, pn, jn);
+                st4<VEC>(gp + 3 * plane, phn, jn);
+            }
+            if (a.h_n && pt == len - 1) st4<VEC>(a.h_n + ((long)l * B + bglob) * H + j0, py, jn);
+        }
+    };
+
     int p = 0;
     const int nticks = T + L - 1;
     for (int tick = 0; tick < nticks; ++tick) {
         const int t = tick - l;
-        if (t >= 0 && t < T) {
+        const bool work = t >= 0 && t < T;
+        if (pend) flush();
+        if (work) {
             const bool active = t < len;
             const float *hb = smem + (long)p * L * NT * 256;
             float4 xin[2], hp[NT];
             if (l == 0) {
                 xin[0] = xn[0]; xin[1] = xn[1];
-                load_x(t + 1);
+                if (t + 1 < T) load_x(t + 1);
             } else {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -152,49 +192,41 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
             for (int q = 0; q < NT; ++q)
                 hp[q] = *reinterpret_cast<const float4 *>(hb + ((l * NT + q) * 64 + lane) * 4);
 
+            // r, z accumulate both products; the candidate keeps W_in x and W_hn h apart.
+            // The chains are interleaved so dependent MFMAs are never back to back.
             f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ain = ar, ahn = ar;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (q < nQin) {
-                    // interleave the three chains so dependent MFMAs are not back to back
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[0][q].x, xin[q].x, ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[1][q].x, xin[q].x, az, 0, 0, 0);
-                    ain = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[2][q].x, xin[q].x, ain, 0, 0, 0);
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[0][q].y, xin[q].y, ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[1][q].y, xin[q].y, az, 0, 0, 0);
-                    ain = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[2][q].y, xin[q].y, ain, 0, 0, 0);
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[0][q].z, xin[q].z, ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[1][q].z, xin[q].z, az, 0, 0, 0);
-                    ain = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[2][q].z, xin[q].z, ain, 0, 0, 0);
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[0][q].w, xin[q].w, ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[1][q].w, xin[q].w, az, 0, 0, 0);
-                    ain = __builtin_amdgcn_mfma_f32_16x16x4f32(wih[2][q].w, xin[q].w, ain, 0, 0, 0);
+                    F4ARR(xv, xin[q]); F4ARR(w0, wih[0][q]); F4ARR(w1, wih[1][q]); F4ARR(w2, wih[2][q]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ar = mf(w0[c], xv[c], ar);
+                        az = mf(w1[c], xv[c], az);
+                        ain = mf(w2[c], xv[c], ain);
+                    }
                 }
             }
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[0][q].x, hp[q].x, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[1][q].x, hp[q].x, az, 0, 0, 0);
-                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[2][q].x, hp[q].x, ahn, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[0][q].y, hp[q].y, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[1][q].y, hp[q].y, az, 0, 0, 0);
-                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[2][q].y, hp[q].y, ahn, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[0][q].z, hp[q].z, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[1][q].z, hp[q].z, az, 0, 0, 0);
-                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[2][q].z, hp[q].z, ahn, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[0][q].w, hp[q].w, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[1][q].w, hp[q].w, az, 0, 0, 0);
-                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(whh[2][q].w, hp[q].w, ahn, 0, 0, 0);
+                F4ARR(hv, hp[q]); F4ARR(w0, whh[0][q]); F4ARR(w1, whh[1][q]); F4ARR(w2, whh[2][q]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ar = mf(w0[c], hv[c], ar);
+                    az = mf(w1[c], hv[c], az);
+                    ahn = mf(w2[c], hv[c], ahn);
+                }
             }
 
+            mfma_drain();
             float rv[4], zv[4], nv[4], hnv[4], yv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float ghn = ahn[c] + bhn[c];
-                const float r = sigm_(ar[c] + brz[0][c]);
-                const float z = sigm_(az[c] + brz[1][c]);
-                const float n = tanhf(ain[c] + bin[c] + r * ghn);
-                const float hnew = (1.f - z) * n + z * hreg[c];
+                const float r = fast_sigmoid(ar[c] + brz[0][c]);
+                const float z = fast_sigmoid(az[c] + brz[1][c]);
+                const float n = fast_tanh(ain[c] + bin[c] + r * ghn);
+                const float hnew = n + z * (hreg[c] - n);
                 rv[c] = r; zv[c] = z; nv[c] = n; hnv[c] = ghn;
                 if (active && c < jn) hreg[c] = hnew;
                 yv[c] = active ? hreg[c] : 0.f;
@@ -202,45 +234,42 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
             float *hw = smem + (long)(p ^ 1) * L * NT * 256;
             *reinterpret_cast<float4 *>(hw + ((l * NT + tile) * 64 + lane) * 4) =
                 make_float4(hreg[0], hreg[1], hreg[2], hreg[3]);
-            if (bvalid && jn > 0) {
-                const long row = (long)t * B + bglob;
-                const float4 y4 = make_float4(yv[0], yv[1], yv[2], yv[3]);
-                if (a.y_int[l]) store4(a.y_int[l] + row * H + j0, y4, jn, hvec);
-                if (l == L - 1 && a.y_ext) {
-                    const long er = map_row(a.ymap, (int)row);
-                    if (er >= 0) store4(a.y_ext + er * H + j0, y4, jn, hvec);
-                }
-                if (a.gates[l] && active) {
-                    float *gp = a.gates[l] + row * H + j0;
-                    store4(gp, make_float4(rv[0], rv[1], rv[2], rv[3]), jn, hvec);
-                    store4(gp + plane, make_float4(zv[0], zv[1], zv[2], zv[3]), jn, hvec);
-                    store4(gp + 2 * plane, make_float4(nv[0], nv[1], nv[2], nv[3]), jn, hvec);
-                    store4(gp + 3 * plane, make_float4(hnv[0], hnv[1], hnv[2], hnv[3]), jn, hvec);
-                }
-                if (a.h_n && t == len - 1) store4(a.h_n + ((long)l * B + bglob) * H + j0, y4, jn, hvec);
-            }
+            py = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            pr = make_float4(rv[0], rv[1], rv[2], rv[3]);
+            pz = make_float4(zv[0], zv[1], zv[2], zv[3]);
+            pn = make_float4(nv[0], nv[1], nv[2], nv[3]);
+            phn = make_float4(hnv[0], hnv[1], hnv[2], hnv[3]);
+            pt = t; pact = active;
         }
+        pend = work;
         lds_barrier();
         p ^= 1;
     }
+    if (pend) flush();
 }
+
+template <int NT, int MAXT>
+static hipError_t launch_fwd_t(const SmallFwdArgs &a, dim3 grid, dim3 block, size_t lds, bool vec, hipStream_t s) {
+    if (vec) hipLaunchKernelGGL((gru_small_fwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gru_small_fwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+static bool all_vec(int In, int H) { return (In & 3) == 0 && (H & 3) == 0; }
 
 hipError_t launch_gru_small_fwd(const SmallFwdArgs &a, hipStream_t s) {
     const int NT = (a.H + 15) / 16;
     dim3 grid(gru_batch_blocks(a.B)), block(64 * NT * a.L);
     const size_t lds = (size_t)2 * a.L * NT * 1024;
-    const bool big = block.x > 512;
-    if (NT == 1 && !big) hipLaunchKernelGGL((gru_small_fwd_kernel<1, 512>), grid, block, lds, s, a);
-    else if (NT == 1) hipLaunchKernelGGL((gru_small_fwd_kernel<1, 1024>), grid, block, lds, s, a);
-    else if (!big) hipLaunchKernelGGL((gru_small_fwd_kernel<2, 512>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_small_fwd_kernel<2, 1024>), grid, block, lds, s, a);
-    return hipGetLastError();
+    const bool big = block.x > 512, vec = all_vec(a.In, a.H);
+    if (NT == 1) return big ? launch_fwd_t<1, 1024>(a, grid, block, lds, vec, s) : launch_fwd_t<1, 512>(a, grid, block, lds, vec, s);
+    return big ? launch_fwd_t<2, 1024>(a, grid, block, lds, vec, s) : launch_fwd_t<2, 512>(a, grid, block, lds, vec, s);
 }
 
 // ----------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------
-template <int NT, int MAXT>
+template <int NT, int MAXT, bool VEC>
 __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
     // gbuf[L][4][NT][256] : da_r | da_z | da_n | da_n*r fragments, dxbuf[2][L][NT][256]
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -255,15 +284,16 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
     const int In_l = (l == 0) ? a.In : H;
     const int nDx = (In_l + 15) / 16;             // dx tiles of this layer
     const bool two_dx = nDx > NT;                 // layer 0 with more input tiles than hidden tiles
-    const bool hvec = (H & 3) == 0;
     const int j0 = 16 * tile + 4 * gq;
     const int jn = min(4, max(0, H - j0));
     const long plane = (long)T * B * H;
-    float *gbuf = smem;
+    float *gb = smem + (long)l * 4 * NT * 256;
     float *dxbuf = smem + (long)L * 4 * NT * 256;
+    const float *wi = a.w_ih[l], *wh = a.w_hh[l], *yint = a.y_int[l], *gates = a.gates[l];
+    float *dgl = a.dg[l];
 
     // A fragments of the transposed weights.
-    //   whhT[g][q]: lane (i, gq), c -> W_hh[G*H + 16q + 4gq + c][16*tile + i], G = r, z, n rows
+    //   whhT[g][q]: lane (i, gq), c -> W_hh[g*H + 16q + 4gq + c][16*tile + i]
     //   wihT[d][g][q]: lane (i, gq), c -> W_ih[g*H + 16q + 4gq + c][16*(tile + d*NT) + i]
     float4 whhT[3][NT], wihT[2][3][NT];
     {
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int kr = 16 * q + 4 * gq + c, oc = 16 * tile + i;
-                    v[c] = (kr < H && oc < H) ? a.w_hh[l][(long)(g * H + kr) * H + oc] : 0.f;
+                    v[c] = (kr < H && oc < H) ? wh[(long)(g * H + kr) * H + oc] : 0.f;
                 }
                 whhT[g][q] = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
@@ -285,8 +315,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int kr = 16 * q + 4 * gq + c, oc = 16 * (tile + d * NT) + i;
-                        u[c] = (kr < H && oc < In_l && (tile + d * NT) < nDx)
-                                   ? a.w_ih[l][(long)(g * H + kr) * In_l + oc] : 0.f;
+                        u[c] = (kr < H && oc < In_l && (d == 0 || two_dx)) ? wi[(long)(g * H + kr) * In_l + oc] : 0.f;
                     }
                     wihT[d][g][q] = make_float4(u[0], u[1], u[2], u[3]);
                 }
@@ -306,24 +335,40 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
         pr = pz = pn = phn = php = pdy = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && t < len && jn > 0) {
             const long row = (long)t * B + bglob;
-            const float *gp = a.gates[l] + row * H + j0;
-            pr = load4(gp, jn, hvec);
-            pz = load4(gp + plane, jn, hvec);
-            pn = load4(gp + 2 * plane, jn, hvec);
-            phn = load4(gp + 3 * plane, jn, hvec);
-            if (t > 0) php = load4(a.y_int[l] + (row - B) * H + j0, jn, hvec);
-            else if (a.h0) php = load4(a.h0 + ((long)l * B + bglob) * H + j0, jn, hvec);
+            const float *gp = gates + row * H + j0;
+            pr = ld4<VEC>(gp, jn);
+            pz = ld4<VEC>(gp + plane, jn);
+            pn = ld4<VEC>(gp + 2 * plane, jn);
+            phn = ld4<VEC>(gp + 3 * plane, jn);
+            if (t > 0) php = ld4<VEC>(yint + (row - B) * H + j0, jn);
+            else if (a.h0) php = ld4<VEC>(a.h0 + ((long)l * B + bglob) * H + j0, jn);
             if (l == L - 1 && a.dy_ext) {
-                const long er = map_row(a.dymap, (int)row);
-                if (er >= 0) pdy = load4(a.dy_ext + er * H + j0, jn, hvec);
+                const long er = map_tb(a.dymap, t, bglob);
+                if (er >= 0) pdy = ld4<VEC>(a.dy_ext + er * H + j0, jn);
             }
             if (a.dh_n && t == len - 1) {
-                const float4 e = load4(a.dh_n + ((long)l * B + bglob) * H + j0, jn, hvec);
+                const float4 e = ld4<VEC>(a.dh_n + ((long)l * B + bglob) * H + j0, jn);
                 pdy.x += e.x; pdy.y += e.y; pdy.z += e.z; pdy.w += e.w;
             }
         }
     };
     prefetch(T - 1);   // every layer starts at t = T-1
+
+    // layer 0: dx of the previous tick, stored at the top of the next one
+    float4 qx0 = make_float4(0.f, 0.f, 0.f, 0.f), qx1 = qx0;
+    int qt = 0;
+    bool qpend = false;
+    auto flush_dx = [&]() {
+        if (a.dx_ext && bvalid) {
+            const long er = map_tb(a.dxmap, qt, bglob);
+            if (er >= 0) {
+                const int c0 = 16 * tile + 4 * gq;
+                if (c0 < a.In) st4<VEC>(a.dx_ext + er * a.In + c0, qx0, a.In - c0);
+                const int c1 = 16 * (tile + NT) + 4 * gq;
+                if (two_dx && c1 < a.In) st4<VEC>(a.dx_ext + er * a.In + c1, qx1, a.In - c1);
+            }
+        }
+    };
 
     int p = 0;
     const int nticks = T + L - 1;
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
         const bool work = t >= 0 && t < T;
         const bool active = work && t < len;
         float keep[4] = {dhc[0], dhc[1], dhc[2], dhc[3]};
-        float *gb = gbuf;
+        if (qpend) { flush_dx(); qpend = false; }
         if (work) {
             float dyv[4] = {pdy.x, pdy.y, pdy.z, pdy.w};
             if (l < L - 1) {   // gradient from the layer above, produced at the previous tick
@@ -340,9 +385,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
                     dxbuf + (long)(p ^ 1) * L * NT * 256 + (((l + 1) * NT + tile) * 64 + lane) * 4);
                 dyv[0] += u.x; dyv[1] += u.y; dyv[2] += u.z; dyv[3] += u.w;
             }
-            const float rr[4] = {pr.x, pr.y, pr.z, pr.w}, zz[4] = {pz.x, pz.y, pz.z, pz.w};
-            const float nn[4] = {pn.x, pn.y, pn.z, pn.w}, hh[4] = {phn.x, phn.y, phn.z, phn.w};
-            const float hq[4] = {php.x, php.y, php.z, php.w};
+            F4ARR(rr, pr); F4ARR(zz, pz); F4ARR(nn, pn); F4ARR(hh, phn); F4ARR(hq, php);
             float dar[4], daz[4], dan[4], dgn[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -362,63 +405,68 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
             const float4 f1 = make_float4(daz[0], daz[1], daz[2], daz[3]);
             const float4 f2 = make_float4(dan[0], dan[1], dan[2], dan[3]);
             const float4 f3 = make_float4(dgn[0], dgn[1], dgn[2], dgn[3]);
-            *reinterpret_cast<float4 *>(gb + (((l * 4 + 0) * NT + tile) * 64 + lane) * 4) = f0;
-            *reinterpret_cast<float4 *>(gb + (((l * 4 + 1) * NT + tile) * 64 + lane) * 4) = f1;
-            *reinterpret_cast<float4 *>(gb + (((l * 4 + 2) * NT + tile) * 64 + lane) * 4) = f2;
-            *reinterpret_cast<float4 *>(gb + (((l * 4 + 3) * NT + tile) * 64 + lane) * 4) = f3;
+            *reinterpret_cast<float4 *>(gb + ((0 * NT + tile) * 64 + lane) * 4) = f0;
+            *reinterpret_cast<float4 *>(gb + ((1 * NT + tile) * 64 + lane) * 4) = f1;
+            *reinterpret_cast<float4 *>(gb + ((2 * NT + tile) * 64 + lane) * 4) = f2;
+            *reinterpret_cast<float4 *>(gb + ((3 * NT + tile) * 64 + lane) * 4) = f3;
             if (bvalid && jn > 0) {
-                float *dst = a.dg[l] + ((long)t * B + bglob) * 4 * H + j0;
-                store4(dst, f0, jn, hvec);
-                store4(dst + H, f1, jn, hvec);
-                store4(dst + 2 * H, f2, jn, hvec);
-                store4(dst + 3 * H, f3, jn, hvec);
+                float *dst = dgl + ((long)t * B + bglob) * 4 * H + j0;
+                st4<VEC>(dst, f0, jn);
+                st4<VEC>(dst + H, f1, jn);
+                st4<VEC>(dst + 2 * H, f2, jn);
+                st4<VEC>(dst + 3 * H, f3, jn);
             }
             prefetch(t - 1);
         }
         lds_barrier();
         if (work) {
-            f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax1 = ah0;
+            // dh_{t-1} += W_hh^T dgh ; dx = W_ih^T dgi.  Four chains, interleaved.
+            f32x4 ah0 = {0.f, 0.f, 0.f, 0.f}, ah1 = ah0, ax0 = ah0, ax2 = ah0, ay0 = ah0, ay2 = ah0;
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                const float4 fr = *reinterpret_cast<const float4 *>(gb + (((l * 4 + 0) * NT + q) * 64 + lane) * 4);
-                const float4 fz = *reinterpret_cast<const float4 *>(gb + (((l * 4 + 1) * NT + q) * 64 + lane) * 4);
-                const float4 fn = *reinterpret_cast<const float4 *>(gb + (((l * 4 + 2) * NT + q) * 64 + lane) * 4);
-                const float4 fg = *reinterpret_cast<const float4 *>(gb + (((l * 4 + 3) * NT + q) * 64 + lane) * 4);
-                MFMA4(ah0, whhT[0][q], fr);
-                MFMA4(ax0, wihT[0][0][q], fr);
-                MFMA4(ah1, whhT[1][q], fz);
-                MFMA4(ax0, wihT[0][1][q], fz);
-                MFMA4(ah0, whhT[2][q], fg);
-                MFMA4(ax0, wihT[0][2][q], fn);
+                const float4 fr4 = *reinterpret_cast<const float4 *>(gb + ((0 * NT + q) * 64 + lane) * 4);
+                const float4 fz4 = *reinterpret_cast<const float4 *>(gb + ((1 * NT + q) * 64 + lane) * 4);
+                const float4 fn4 = *reinterpret_cast<const float4 *>(gb + ((2 * NT + q) * 64 + lane) * 4);
+                const float4 fg4 = *reinterpret_cast<const float4 *>(gb + ((3 * NT + q) * 64 + lane) * 4);
+                F4ARR(fr, fr4); F4ARR(fz, fz4); F4ARR(fn, fn4); F4ARR(fg, fg4);
+                F4ARR(h0w, whhT[0][q]); F4ARR(h1w, whhT[1][q]); F4ARR(h2w, whhT[2][q]);
+                F4ARR(x0w, wihT[0][0][q]); F4ARR(x1w, wihT[0][1][q]); F4ARR(x2w, wihT[0][2][q]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ah0 = mf(h0w[c], fr[c], ah0);
+                    ax0 = mf(x0w[c], fr[c], ax0);
+                    ah1 = mf(h1w[c], fz[c], ah1);
+                    ax2 = mf(x1w[c], fz[c], ax2);
+                    ah0 = mf(h2w[c], fg[c], ah0);
+                    ax0 = mf(x2w[c], fn[c], ax0);
+                }
+                mfma_drain();
                 if (two_dx) {
-                    MFMA4(ax1, wihT[1][0][q], fr);
-                    MFMA4(ax1, wihT[1][1][q], fz);
-                    MFMA4(ax1, wihT[1][2][q], fn);
+                    F4ARR(y0w, wihT[1][0][q]); F4ARR(y1w, wihT[1][1][q]); F4ARR(y2w, wihT[1][2][q]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ay0 = mf(y0w[c], fr[c], ay0);
+                        ay2 = mf(y1w[c], fz[c], ay2);
+                        ay0 = mf(y2w[c], fn[c], ay0);
+                    }
                 }
             }
+            mfma_drain();
 #pragma unroll
             for (int c = 0; c < 4; ++c) dhc[c] = keep[c] + (active ? ah0[c] + ah1[c] : 0.f);
+            const float4 dx0 = make_float4(ax0[0] + ax2[0], ax0[1] + ax2[1], ax0[2] + ax2[2], ax0[3] + ax2[3]);
             if (l > 0) {
-                *reinterpret_cast<float4 *>(dxbuf + (long)p * L * NT * 256 + ((l * NT + tile) * 64 + lane) * 4) =
-                    make_float4(ax0[0], ax0[1], ax0[2], ax0[3]);
-            } else if (a.dx_ext && bvalid) {
-                const long er = map_row(a.dxmap, t * B + bglob);
-                if (er >= 0) {
-                    const bool xvec = (a.In & 3) == 0;
-                    const int c0 = 16 * tile + 4 * gq;
-                    if (c0 < a.In)
-                        store4(a.dx_ext + er * a.In + c0, make_float4(ax0[0], ax0[1], ax0[2], ax0[3]),
-                               min(4, a.In - c0), xvec);
-                    const int c1 = 16 * (tile + NT) + 4 * gq;
-                    if (tile + NT < nDx && c1 < a.In)
-                        store4(a.dx_ext + er * a.In + c1, make_float4(ax1[0], ax1[1], ax1[2], ax1[3]),
-                               min(4, a.In - c1), xvec);
-                }
+                *reinterpret_cast<float4 *>(dxbuf + (long)p * L * NT * 256 + ((l * NT + tile) * 64 + lane) * 4) = dx0;
+            } else {
+                qx0 = dx0;
+                qx1 = make_float4(ay0[0] + ay2[0], ay0[1] + ay2[1], ay0[2] + ay2[2], ay0[3] + ay2[3]);
+                qt = t; qpend = true;
             }
         }
         lds_barrier();
         p ^= 1;
     }
+    if (qpend) flush_dx();
 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -432,33 +480,39 @@ __global__ __launch_bounds__(MAXT) void gru_small_bwd_kernel(SmallBwdArgs a) {
     }
 }
 
-hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s) {
-    const int NT = (a.H + 15) / 16;
-    dim3 grid(gru_batch_blocks(a.B)), block(64 * NT * a.L);
-    const size_t lds = ((size_t)a.L * 4 * NT + (size_t)2 * a.L * NT) * 1024;
-    const bool big = block.x > 512;
-    const void *fn = NT == 1 ? (big ? (const void *)gru_small_bwd_kernel<1, 1024> : (const void *)gru_small_bwd_kernel<1, 512>)
-                             : (big ? (const void *)gru_small_bwd_kernel<2, 1024> : (const void *)gru_small_bwd_kernel<2, 512>);
+template <int NT, int MAXT>
+static hipError_t launch_bwd_t(const SmallBwdArgs &a, dim3 grid, dim3 block, size_t lds, bool vec, hipStream_t s) {
+    const void *fn = vec ? (const void *)gru_small_bwd_kernel<NT, MAXT, true>
+                         : (const void *)gru_small_bwd_kernel<NT, MAXT, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (NT == 1 && !big) hipLaunchKernelGGL((gru_small_bwd_kernel<1, 512>), grid, block, lds, s, a);
-    else if (NT == 1) hipLaunchKernelGGL((gru_small_bwd_kernel<1, 1024>), grid, block, lds, s, a);
-    else if (!big) hipLaunchKernelGGL((gru_small_bwd_kernel<2, 512>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_small_bwd_kernel<2, 1024>), grid, block, lds, s, a);
+    if (vec) hipLaunchKernelGGL((gru_small_bwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gru_small_bwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s) {
+    const int NT = (a.H + 15) / 16;
+    dim3 grid(gru_batch_blocks(a.B)), block(64 * NT * a.L);
+    const size_t lds = ((size_t)a.L * 4 * NT + (size_t)2 * a.L * NT) * 1024;
+    const bool big = block.x > 512, vec = all_vec(a.In, a.H);
+    if (NT == 1) return big ? launch_bwd_t<1, 1024>(a, grid, block, lds, vec, s) : launch_bwd_t<1, 512>(a, grid, block, lds, vec, s);
+    return big ? launch_bwd_t<2, 1024>(a, grid, block, lds, vec, s) : launch_bwd_t<2, 512>(a, grid, block, lds, vec, s);
 }
 
 // ----------------------------------------------------------------------------------------------
 // weight gradients of all layers in one launch
 // ----------------------------------------------------------------------------------------------
-// One workgroup per 16x16 output tile of dW_ih / dW_hh (plus one per layer for the biases); its 8
+// One workgroup per 16x16 output tile of dW_ih / dW_hh (plus one per layer for the biases); its 16
 // waves split the T*B reduction rows, partial tiles are summed through LDS in a fixed order.
 //   dW_ih[m][n] = sum_k dg[k][m] * xin[k][n]                     m < 3H
 //   dW_hh[m][n] = sum_k dg[k][cm(m)] * h_{t-1}[k][n]             cm(m) = m < 2H ? m : m + H
-__global__ __launch_bounds__(512) void gru_small_wgrad_kernel(SmallWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[8][64][4];
+constexpr int kWgWaves = 16;
+
+__global__ __launch_bounds__(64 * kWgWaves) void gru_small_wgrad_kernel(SmallWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[kWgWaves][64][4];
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -467,8 +521,9 @@ __global__ __launch_bounds__(512) void gru_small_wgrad_kernel(SmallWgradArgs a) 
     int job = blockIdx.x, l = 0, kind = -1, mt = 0, nt = 0;
     for (l = 0; l < L; ++l) {
         const int In_l = (l == 0) ? a.In : H;
-        const int n_ih = Mt * ((In_l + 15) / 16), n_hh = Mt * NtH;
-        if (job < n_ih) { kind = 0; mt = job / ((In_l + 15) / 16); nt = job % ((In_l + 15) / 16); break; }
+        const int nti = (In_l + 15) / 16;
+        const int n_ih = Mt * nti, n_hh = Mt * NtH;
+        if (job < n_ih) { kind = 0; mt = job / nti; nt = job % nti; break; }
         job -= n_ih;
         if (job < n_hh) { kind = 1; mt = job / NtH; nt = job % NtH; break; }
         job -= n_hh;
@@ -500,21 +555,22 @@ __global__ __launch_bounds__(512) void gru_small_wgrad_kernel(SmallWgradArgs a) 
     const bool nok = n < N;
     const float *dg = a.dg[l];
     const float *src = kind == 0 ? (l == 0 ? a.x : a.y_int[l - 1]) : a.y_int[l];
-    const int kchunk = ((K + 7) / 8 + 3) / 4 * 4;
+    const bool mapped = kind == 0 && l == 0 && a.xmap.mode != 0;
+    const int kchunk = ((K + kWgWaves - 1) / kWgWaves + 3) / 4 * 4;
     const int kbeg = wave * kchunk, kend = min(K, kbeg + kchunk);
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        float av[4], bv[4];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        float av[16], bv[16];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
+        for (int s4 = 0; s4 < 16; ++s4) {
             const int k = k0 + 4 * s4 + gq;
             av[s4] = 0.f; bv[s4] = 0.f;
             if (k < kend) {
                 if (mok) av[s4] = dg[(long)k * 4 * H + acol];
                 if (nok) {
                     if (kind == 0) {
-                        const long er = (l == 0) ? map_row(a.xmap, k) : (long)k;
+                        const long er = mapped ? map_row(a.xmap, k) : (long)k;
                         if (er >= 0) bv[s4] = src[er * N + n];
                     } else {
                         if (k >= B) bv[s4] = src[(long)(k - B) * H + n];
@@ -524,15 +580,18 @@ __global__ __launch_bounds__(512) void gru_small_wgrad_kernel(SmallWgradArgs a) 
             }
         }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4], acc, 0, 0, 0);
+        for (int s4 = 0; s4 < 16; s4 += 2) {
+            acc0 = mf(av[s4], bv[s4], acc0);
+            acc1 = mf(av[s4 + 1], bv[s4 + 1], acc1);
+        }
     }
-    *reinterpret_cast<float4 *>(&red[wave][lane][0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    mfma_drain();
+    *reinterpret_cast<float4 *>(&red[wave][lane][0]) =
+        make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
     __syncthreads();
     if (wave == 0) {
         float4 s = *reinterpret_cast<const float4 *>(&red[0][lane][0]);
-        const int nw = blockDim.x >> 6;
-        for (int w = 1; w < nw; ++w) {
+        for (int w = 1; w < kWgWaves; ++w) {
             const float4 v = *reinterpret_cast<const float4 *>(&red[w][lane][0]);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -557,7 +616,7 @@ hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
         const int In_l = l == 0 ? a.In : a.H;
         jobs += Mt * ((In_l + 15) / 16) + Mt * NtH + 1;
     }
-    hipLaunchKernelGGL(gru_small_wgrad_kernel, dim3(jobs), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(gru_small_wgrad_kernel, dim3(jobs), dim3(64 * kWgWaves), 0, s, a);
     return hipGetLastError();
 }
 

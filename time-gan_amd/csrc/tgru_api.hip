@@ -171,8 +171,12 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
     if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (reserve && !aligned16(reserve)) ||
         (h_n && !aligned16(h_n)))
         return TGRU_E_ALIGN;
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < L; ++l) {
         if (!w_ih[l] || !w_hh[l] || !b_ih[l] || !b_hh[l]) return TGRU_E_NULL;
+        if (!aligned16(w_ih[l]) || !aligned16(w_hh[l]) || !aligned16(b_ih[l]) || !aligned16(b_hh[l]))
+            return TGRU_E_ALIGN;
+    }
+    if (h0 && !aligned16(h0)) return TGRU_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     float *gi = workspace;
@@ -242,8 +246,11 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || !aligned16(reserve) ||
         (dy && !aligned16(dy)) || (dx && !aligned16(dx)))
         return TGRU_E_ALIGN;
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < L; ++l) {
         if (!w_ih[l] || !w_hh[l] || !dw_ih[l] || !dw_hh[l] || !db_ih[l] || !db_hh[l]) return TGRU_E_NULL;
+        if (!aligned16(w_ih[l]) || !aligned16(w_hh[l])) return TGRU_E_ALIGN;
+    }
+    if ((h0 && !aligned16(h0)) || (dh_n && !aligned16(dh_n)) || (dh0 && !aligned16(dh0))) return TGRU_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     const BwdWs w = bwd_ws(d);

@@ -25,6 +25,27 @@ __device__ __forceinline__ long map_row(const RowMap &rm, int m) {
     return (b < rm.toff[t + 1] - o) ? (long)(o + b) : -1L;
 }
 
+// same mapping from (t, b) directly (no division)
+__device__ __forceinline__ long map_tb(const RowMap &rm, int t, int b) {
+    if (rm.mode == 0) return (long)t * rm.B + b;
+    if (rm.mode == 1) return (long)b * rm.T + t;
+    const int o = rm.toff[t];
+    return (b < rm.toff[t + 1] - o) ? (long)(o + b) : -1L;
+}
+
+// Gate nonlinearities on the hardware exp2 / rcp units (about 1 ulp each).
+__device__ __forceinline__ float fast_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float a = fabsf(v);
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177793f * a);
+    const float big = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+    const float a2 = a * a;   // odd Taylor polynomial below 0.25, where 1 - e cancels
+    const float small = a * (1.f + a2 * (-0.333333333f + a2 * (0.133333333f + a2 * (-0.0539682540f + a2 * 0.0218694885f))));
+    return copysignf(a < 0.25f ? small : big, v);
+}
+
 // ----------------------------------------------------------------------------------------------
 // fp32 MFMA GEMM:  C(m,n) [+]= sum_k A(m,k) * B(k,n)  (+ bias[n])
 //   a_kc: A element (m,k) is at A[arow(m)*lda + k]  (k contiguous), else at A[k*lda + m]
