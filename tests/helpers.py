@@ -39,11 +39,11 @@ def expected(case, tag):
     return out
 
 
-def assert_close(got, ref, rtol, atol_scale, what):
+def assert_close(got, ref, rtol, atol_scale, what, atol_abs=0.0):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
-    atol = atol_scale * max(float(np.abs(ref).max()), 1e-30)
+    atol = atol_scale * max(float(np.abs(ref).max()), 1e-30) + atol_abs
     err = np.abs(got - ref)
     bad = err > atol + rtol * np.abs(ref)
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.size} elements out of tolerance, "

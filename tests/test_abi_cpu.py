@@ -1,0 +1,84 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol the header declares,
+its size queries behave, and the host-side argument validation mirrors torch's errors.
+No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tgru.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgru_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import timegan_amd as tg
+    from timegan_amd import _lib
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert declared, "no declarations parsed from include/tgru.h"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/tgru.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "python binding table and header disagree"
+    assert tg.lib().tgru_version() >= 100
+
+
+def test_size_queries_and_error_strings():
+    import timegan_amd as tg
+    lb = tg.lib()
+    B, T, In, H, L = 128, 24, 24, 24, 3
+    tbh = B * T * H * 4
+    # 4 gate planes per layer + (L-1) intermediate outputs (+1 copy when the layout is not time-major)
+    assert lb.tgru_reserve_bytes(B, T, In, H, L, tg.LAYOUT_TBF) >= (4 * L + L - 1) * tbh
+    assert lb.tgru_reserve_bytes(B, T, In, H, L, tg.LAYOUT_BTF) >= (4 * L + L) * tbh
+    assert lb.tgru_forward_workspace_bytes(B, T, In, H, L) > 0
+    assert lb.tgru_backward_workspace_bytes(B, T, In, H, L) > 0
+    assert lb.tgru_reserve_bytes(0, T, In, H, L, 0) == 0            # bad dims -> 0
+    assert lb.tgru_reserve_bytes(B, T, In, 4096, L, 0) == 0         # hidden size beyond the built range
+    assert lb.tgru_error_string(0) == b"ok"
+    for code in range(-6, 0):
+        assert lb.tgru_error_string(code) not in (b"ok", b"unknown error")
+    # NULL pointers are rejected before anything is launched
+    rc = lb.tgru_forward(None, None, None, None, None, None, None, None, None, None, None, None,
+                         B, T, In, H, L, 0, None)
+    assert rc == -2
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    import timegan_amd as tg
+    gru = tg.GRU(4, 8, 1, batch_first=True)
+    with pytest.raises(tg.TgruError, match="no CPU fallback"):
+        gru(torch.zeros(2, 3, 4))
+
+
+def test_lengths_validation_matches_torch_messages():
+    from timegan_amd.functional import lengths_to_device
+    assert lengths_to_device([5, 5, 5], 3, 5, "cpu") is None
+    assert lengths_to_device(torch.ones(3) * 5, 3, 5, "cpu") is None       # float tensor accepted
+    out = lengths_to_device([5, 3, 1], 3, 5, "cpu")
+    assert out.dtype == torch.int32 and out.tolist() == [5, 3, 1]
+    with pytest.raises(RuntimeError, match="sorted in decreasing order"):
+        lengths_to_device([1, 3, 5], 3, 5, "cpu")
+    with pytest.raises(RuntimeError, match="greater than 0"):
+        lengths_to_device([3, 1, 0], 3, 5, "cpu")
+
+
+def test_gru_module_matches_torch_parameter_layout_and_init():
+    import timegan_amd as tg
+    torch.manual_seed(3)
+    ours = tg.GRU(6, 24, 3, batch_first=True)
+    torch.manual_seed(3)
+    ref = torch.nn.GRU(6, 24, 3, batch_first=True)
+    sd_o, sd_r = ours.state_dict(), ref.state_dict()
+    assert list(sd_o) == list(sd_r)
+    for k in sd_r:
+        assert sd_o[k].shape == sd_r[k].shape
+        assert torch.equal(sd_o[k], sd_r[k]), f"{k}: same seed must give the same initial values"
+    ref.load_state_dict(sd_o)       # interchange both ways
+    ours.load_state_dict(sd_r)

@@ -1,0 +1,111 @@
+"""Data-parallel path on CPU: 2 ranks over gloo must reproduce the single-process result on the
+concatenated batch (losses, the D-step branch and the parameters after the step), including the
+sqrt-of-global-mse and global-batch-moment terms.  The networks run on torch.nn.GRU here; the
+collective logic under test is the same code that runs over RCCL on GPUs."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_trainer(group=None):
+    import timegan_amd as tg
+    torch.manual_seed(5)
+    cfg = tg.make_cfg(features=5, hidden=12, layers=2, seq_len=8, device="cpu")
+    return tg.TimeGANTrainer(cfg, device="cpu", rnn_cls=torch.nn.GRU, group=group)
+
+
+def _data():
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(6, 8, 5, generator=g)           # uneven shards: 3 + 3 with world 2; 6 = global batch
+    noise = [torch.rand(6, 8, 5, generator=g) for _ in range(11)]
+    return x, noise
+
+
+def _generator_grads(tr, x, z):
+    """Gradients of the generator loss (the one with sqrt-of-mse and batch-moment terms), summed
+    over ranks, before any optimiser step."""
+    from timegan_amd import losses, parallel
+    n = tr.nets
+    for m in n.values():
+        m.zero_grad()
+    loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, tr.lengths_of(x), z,
+                                    group=tr.group)
+    loss.backward()
+    parallel.all_reduce_grads(n.values(), group=tr.group)
+    grads = {f"{k}.{name}": p.grad.clone() for k, m in n.items() for name, p in m.named_parameters()
+             if p.grad is not None}
+    return float(loss.detach()), grads
+
+
+def _run_steps(tr, x, noise):
+    out = {"emb": tr.embedding_step(x), "sup": tr.supervisor_step(x)}
+    j = tr.joint_step(x, noise=noise)
+    out.update(g=j["g_loss"], e=j["e_loss"], d=j["d_loss"], d_stepped=j["d_stepped"])
+    return out
+
+
+def _worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from timegan_amd import parallel
+    tr = _make_trainer()
+    x, noise = _data()
+    xs = parallel.shard_batch(x)
+    ns = [parallel.shard_batch(z) for z in noise]
+    gl, gg = _generator_grads(tr, xs, ns[0])
+    out = _run_steps(tr, xs, ns)
+    if rank == 0:
+        torch.save({"out": out, "sd": tr.state_dicts(), "g_loss0": gl, "g_grads0": gg}, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    torch.set_num_threads(1)
+    tr = _make_trainer()
+    x, noise = _data()
+    ref_gl, ref_gg = _generator_grads(tr, x, noise[0])
+    ref = _run_steps(tr, x, noise)
+    ref_sd = tr.state_dicts()
+
+    path = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = torch.load(path, weights_only=False)
+
+    # exactness of the sharded loss and of the rank-summed gradients, before Adam amplifies anything
+    assert abs(got["g_loss0"] - ref_gl) <= 1e-5 * abs(ref_gl)
+    assert set(got["g_grads0"]) == set(ref_gg)
+    for name, g in ref_gg.items():
+        scale = float(g.abs().max())
+        np.testing.assert_allclose(got["g_grads0"][name].numpy(), g.numpy(), rtol=1e-4, atol=1e-5 * scale + 1e-9,
+                                   err_msg=name)
+    assert got["out"]["d_stepped"] == ref["d_stepped"]
+    for k in ("emb", "sup"):      # first optimiser step of each phase: losses still agree tightly
+        assert abs(got["out"][k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-6, k
+    assert abs(got["out"]["d"] - ref["d"]) <= 2e-3 * abs(ref["d"])     # after 20 Adam steps
+    np.testing.assert_allclose(got["out"]["g"], ref["g"], rtol=2e-3)
+    np.testing.assert_allclose(got["out"]["e"], ref["e"], rtol=2e-3)
+    for net, sd in ref_sd.items():
+        for name, p in sd.items():
+            np.testing.assert_allclose(got["sd"][net][name].numpy(), p.numpy(), rtol=5e-3, atol=5e-4,
+                                       err_msg=f"{net}.{name}")
+
+
+def test_shard_batch_covers_everything_once():
+    from timegan_amd import parallel
+    x = torch.arange(7)
+    assert parallel.shard_batch(x).tolist() == list(range(7))      # world 1: identity

@@ -1,0 +1,182 @@
+"""Host-side mirrors (modules, loss builders, three-phase steps) against fixtures captured from the
+imported reference (tests/golden/make_golden.py).
+
+On CPU the networks are built on torch.nn.GRU (`rnn_cls`), which checks the host logic alone; the
+GPU variants of the same tests build them on the HIP GRU and check the whole product path.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, assert_close
+
+NETS = ("emb", "rec", "sup", "g", "d")
+
+
+def _cfg(threshold=0.15):
+    import timegan_amd as tg
+    return tg.make_cfg(features=5, hidden=24, layers=3, seq_len=24, threshold=threshold, device="cpu")
+
+
+def _load_sd(d, prefix, nets, device):
+    for k in NETS:
+        sd = {key[len(prefix) + len(k) + 1:]: torch.from_numpy(d[key]).to(device)
+              for key in d.files if key.startswith(f"{prefix}{k}.")}
+        nets[k].load_state_dict(sd)
+
+
+def _build(device, on_gpu):
+    import timegan_amd as tg
+    kw = {} if on_gpu else {"rnn_cls": torch.nn.GRU}
+    nets = tg.build_networks(_cfg(), **kw)
+    return {k: m.to(device) for k, m in nets.items()}
+
+
+def _check_grads(d, tag, nets, rtol, atol_scale):
+    for k in NETS:
+        for name, p in nets[k].named_parameters():
+            key = f"{tag}.{k}.{name}"
+            if key not in d.files:
+                continue
+            got = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.cpu().numpy()
+            assert_close(got, d[key], rtol, atol_scale, key)
+
+
+def _modules(device, on_gpu):
+    d = np.load(os.path.join(GOLDEN, "modules_c1.npz"))
+    nets = _build(device, on_gpu)
+    _load_sd(d, "sd.", nets, device)
+    for tag in ("full", "ragged"):
+        t = [int(v) for v in d[f"{tag}.t"]]
+        for k in NETS:
+            nets[k].zero_grad()
+            xin = torch.from_numpy(d[f"{tag}.{k}.in"]).to(device).requires_grad_(True)
+            y = nets[k](xin, t)
+            assert_close(y.detach().cpu().numpy(), d[f"{tag}.{k}.out"], 1e-5, 2e-6, f"{tag}.{k}.out")
+            (y * torch.from_numpy(d[f"{tag}.{k}.gout"]).to(device)).sum().backward()
+            assert_close(xin.grad.cpu().numpy(), d[f"{tag}.{k}.gin"], 1e-4, 1e-5, f"{tag}.{k}.gin")
+            for name, p in nets[k].named_parameters():
+                assert_close(p.grad.cpu().numpy(), d[f"{tag}.{k}.grad.{name}"], 1e-4, 1e-5,
+                             f"{tag}.{k}.grad.{name}")
+
+
+def _losses(device, on_gpu):
+    import timegan_amd as tg
+    L = tg.losses
+    d = np.load(os.path.join(GOLDEN, "losses_c1.npz"))
+    nets = _build(device, on_gpu)
+    _load_sd(d, "sd.", nets, device)
+    x = torch.from_numpy(d["x"]).to(device)
+    z = torch.from_numpy(d["z"]).to(device)
+    t = [int(v) for v in d["t"]]
+    n = nets
+
+    def zero():
+        for m in nets.values():
+            m.zero_grad()
+
+    zero()
+    e0, xt = L.embedding_forward_side(n["emb"], n["rec"], x, t)
+    e0.backward()
+    assert_close(e0.item(), d["side.e_loss0"], 1e-5, 0, "side.e_loss0")
+    assert_close(xt.detach().cpu().numpy(), d["side.x_tilde"], 1e-5, 2e-6, "side.x_tilde")
+    _check_grads(d, "side.grad", nets, 1e-4, 2e-5)
+
+    zero()
+    e, e0, et0 = L.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t)
+    e.backward()
+    assert_close(e.item(), d["main.e_loss"], 1e-5, 0, "main.e_loss")
+    assert_close(et0.item(), d["main.e_loss_t0"], 1e-5, 0, "main.e_loss_t0")
+    _check_grads(d, "main.grad", nets, 1e-4, 2e-5)
+
+    zero()
+    s, h, hs = L.supervisor_forward(n["emb"], n["sup"], x, t)
+    s.backward()
+    assert_close(s.item(), d["sup.s_loss"], 1e-5, 0, "sup.s_loss")
+    assert_close(hs.detach().cpu().numpy(), d["sup.h_sup"], 1e-5, 2e-6, "sup.h_sup")
+    _check_grads(d, "sup.grad", nets, 1e-4, 2e-5)
+
+    zero()
+    dl = L.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z)
+    dl.backward()
+    assert_close(dl.item(), d["disc.d_loss"], 1e-5, 0, "disc.d_loss")
+    _check_grads(d, "disc.grad", nets, 1e-4, 2e-5)
+
+    zero()
+    gl = L.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z)
+    gl.backward()
+    assert_close(gl.item(), d["gen.g_loss"], 1e-5, 0, "gen.g_loss")
+    _check_grads(d, "gen.grad", nets, 1e-4, 2e-5)
+
+    with torch.no_grad():
+        xh = L.inference(n["sup"], n["g"], n["rec"], z, t)
+    assert_close(xh.cpu().numpy(), d["inference.x_hat"], 1e-5, 2e-6, "inference.x_hat")
+
+
+def _steps(device, on_gpu):
+    """embedding x3, supervisor x3, joint x2 (D steps), joint x1 with a high threshold (D skipped)."""
+    import timegan_amd as tg
+    d = np.load(os.path.join(GOLDEN, "steps_c1.npz"))
+    kw = {} if on_gpu else {"rnn_cls": torch.nn.GRU}
+    tr = tg.TimeGANTrainer(_cfg(), device=device, **kw)
+    _load_sd(d, "init.", tr.nets, device)
+
+    def check_params(tag, rtol, atol_abs):
+        # Adam moves every parameter by about lr = 1e-3 per step whatever the gradient's size, so a
+        # rounding-level difference in a near-zero gradient shows up as a fraction of lr in the
+        # parameter: the absolute tolerance is a fraction of lr, on top of a relative one.
+        for k in NETS:
+            for name, p in tr.nets[k].state_dict().items():
+                assert_close(p.cpu().numpy(), d[f"{tag}.{k}.{name}"], rtol, 0.0, f"{tag}.{k}.{name}",
+                             atol_abs=atol_abs)
+
+    got = [tr.embedding_step(torch.from_numpy(xb).to(device)) for xb in d["embedding.x"]]
+    assert_close(got, d["embedding.e_loss0"], 1e-4, 0, "embedding losses")
+    check_params("after_embedding", 1e-3, 1e-4)
+
+    got = [tr.supervisor_step(torch.from_numpy(xb).to(device)) for xb in d["supervisor.x"]]
+    assert_close(got, d["supervisor.s_loss"], 1e-4, 0, "supervisor losses")
+    check_params("after_supervisor", 1e-3, 1e-4)
+
+    for tag in ("joint", "joint_skip_d"):
+        tr.d_threshold = float(d[f"{tag}.threshold"])
+        zs = [torch.from_numpy(z).to(device) for z in d[f"{tag}.z"]]
+        g_all, e_all, d_all = [], [], []
+        for i, xb in enumerate(d[f"{tag}.x"]):
+            out = tr.joint_step(torch.from_numpy(xb).to(device), noise=zs[11 * i:11 * i + 11])
+            g_all += out["g_loss"]; e_all += out["e_loss"]; d_all.append(out["d_loss"])
+            assert out["d_stepped"] == (tag == "joint")
+        # after tens of Adam steps losses are compared at 1e-3, parameters at half a learning rate
+        assert_close(g_all, d[f"{tag}.g_loss"], 1e-3, 0, f"{tag} g losses")
+        assert_close(e_all, d[f"{tag}.e_loss"], 1e-3, 0, f"{tag} e losses")
+        assert_close(d_all, d[f"{tag}.d_loss"], 1e-3, 0, f"{tag} d losses")
+        check_params(f"after_{tag}", 5e-3, 5e-4)
+
+
+def test_modules_match_reference_cpu():
+    _modules(torch.device("cpu"), False)
+
+
+def test_losses_match_reference_cpu():
+    _losses(torch.device("cpu"), False)
+
+
+def test_training_steps_match_reference_cpu():
+    _steps(torch.device("cpu"), False)
+
+
+@pytest.mark.gpu
+def test_modules_match_reference_gpu():
+    _modules(torch.device("cuda:0"), True)
+
+
+@pytest.mark.gpu
+def test_losses_match_reference_gpu():
+    _losses(torch.device("cuda:0"), True)
+
+
+@pytest.mark.gpu
+def test_training_steps_match_reference_gpu():
+    _steps(torch.device("cuda:0"), True)

@@ -2,3 +2,7 @@
 from ._lib import TgruError, lib, LAYOUT_TBF, LAYOUT_BTF, LAYOUT_PACKED  # noqa: F401
 from .functional import GRURunner, gru_forward_backward_raw, gru_apply, input_projection  # noqa: F401
 from .gru import GRU  # noqa: F401
+from .modules import (Embedding, Recovery, Supervisor, Generator, Discriminator,  # noqa: F401
+                      build_networks, make_cfg)
+from . import losses, parallel  # noqa: F401
+from .trainer import TimeGANTrainer  # noqa: F401

@@ -69,6 +69,27 @@ __device__ __forceinline__ f32x4 mf(float a, float b, f32x4 c) {
 
 #define F4ARR(name, v) const float name[4] = {(v).x, (v).y, (v).z, (v).w}
 
+// Diagnostic build only (make stamps): per-wave cycle shares of the forward tick, read back with
+// tgru_debug_stamps().  No stamp executes in the product library.
+#ifdef TGRU_STAMPS
+__device__ unsigned long long tgru_stamps[16 * 8];
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(k)                                                   \
+    do {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += now_ - st_last; st_last = now_;               \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+#define STAMP_FLUSH                                                          \
+    if (blockIdx.x == 0 && lane == 0)                                        \
+        for (int k_ = 0; k_ < 6; ++k_) tgru_stamps[wave * 8 + k_] = st_acc[k_];
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
@@ -171,10 +192,13 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
 
     int p = 0;
     const int nticks = T + L - 1;
+    STAMP_DECL
     for (int tick = 0; tick < nticks; ++tick) {
         const int t = tick - l;
         const bool work = t >= 0 && t < T;
+        STAMP(5);
         if (pend) flush();
+        STAMP(0);
         if (work) {
             const bool active = t < len;
             const float *hb = smem + (long)p * L * NT * 256;
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
 
             // r, z accumulate both products; the candidate keeps W_in x and W_hn h apart.
             // The chains are interleaved so dependent MFMAs are never back to back.
+            STAMP(1);
             f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ain = ar, ahn = ar;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -219,6 +244,7 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
             }
 
             mfma_drain();
+            STAMP(2);
             float rv[4], zv[4], nv[4], hnv[4], yv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -242,11 +268,20 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
             pt = t; pact = active;
         }
         pend = work;
+        STAMP(3);
         lds_barrier();
+        STAMP(4);
         p ^= 1;
     }
     if (pend) flush();
+    STAMP_FLUSH
 }
+
+#ifdef TGRU_STAMPS
+extern "C" int tgru_debug_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgru_stamps), sizeof(unsigned long long) * 16 * 8);
+}
+#endif
 
 template <int NT, int MAXT>
 static hipError_t launch_fwd_t(const SmallFwdArgs &a, dim3 grid, dim3 block, size_t lds, bool vec, hipStream_t s) {

@@ -1,0 +1,116 @@
+"""The loss builders of TimeGAN, mirrors of outdated_files/TimeGANv1.py:410-570.
+
+Each function returns what its reference counterpart returns.  With one process they make the same
+torch calls as the reference.  Under data parallelism (`group` with more than one rank) every mean
+over the batch is rebuilt from all-reduced sums so that the value -- and, with gradients summed over
+ranks, the gradient -- equals the single-process result on the concatenated batch:
+  * sqrt(mse) terms (TimeGANv1.py:420-421,448-449,551): the mse is global before the sqrt;
+  * the moment loss (TimeGANv1.py:543-548): batch mean and population std come from global sums;
+  * BCE and plain MSE means: global sum / global count.
+"""
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .parallel import dist_sum, world_size
+
+
+def _count(t: torch.Tensor, group) -> torch.Tensor:
+    n = torch.tensor(float(t.numel()), device=t.device)
+    return dist_sum(n, group) if world_size(group) > 1 else n
+
+
+def _mse(a: torch.Tensor, b: torch.Tensor, group=None) -> torch.Tensor:
+    if world_size(group) == 1:
+        return F.mse_loss(a, b)
+    return dist_sum(((a - b) ** 2).sum(), group) / _count(a, group)
+
+
+def _bce_logits(y: torch.Tensor, target_one: bool, group=None) -> torch.Tensor:
+    target = torch.ones_like(y) if target_one else torch.zeros_like(y)
+    if world_size(group) == 1:
+        return F.binary_cross_entropy_with_logits(y, target)
+    s = F.binary_cross_entropy_with_logits(y, target, reduction="sum")
+    return dist_sum(s, group) / _count(y, group)
+
+
+def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mean(dim=0) and std(dim=0, unbiased=False) over the GLOBAL batch."""
+    if world_size(group) == 1:
+        return v.mean(dim=0), v.std(dim=0, unbiased=False)
+    # Everything computed after a dist_sum must be the same on every rank (its backward is the
+    # identity), so the variance comes from all-reduced raw moments, taken about a constant close to
+    # the mean (the detached global mean) to keep E[d^2] - E[d]^2 free of cancellation.
+    n = dist_sum(torch.tensor(float(v.shape[0]), device=v.device), group)
+    c = (dist_sum(v.detach().sum(dim=0), group) / n).detach()
+    dlt = v - c
+    m1 = dist_sum(dlt.sum(dim=0), group) / n
+    m2 = dist_sum((dlt * dlt).sum(dim=0), group) / n
+    return c + m1, torch.sqrt(torch.clamp(m2 - m1 * m1, min=0.0))
+
+
+def embedding_forward_side(emb, rec, x, t, group=None):
+    """TimeGANv1.py:410-423 -> (e_loss0, x_tilde)."""
+    h = emb(x, t)
+    x_tilde = rec(h, t)
+    e_loss_t0 = _mse(x_tilde, x, group)
+    return 10 * torch.sqrt(e_loss_t0), x_tilde
+
+
+def embedding_forward_main(emb, sup, rec, x, t, group=None):
+    """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0)."""
+    h = emb(x, t)
+    x_tilde = rec(h, t)
+    h_sup = sup(h, t)
+    g_loss_sup = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
+    e_loss_t0 = _mse(x_tilde, x, group)
+    e_loss0 = 10 * torch.sqrt(e_loss_t0)
+    return e_loss0 + 0.1 * g_loss_sup, e_loss0, e_loss_t0
+
+
+def supervisor_forward(emb, sup, x, t, group=None):
+    """TimeGANv1.py:454-472 -> (s_loss, h, h_sup)."""
+    h = emb(x, t)
+    h_sup = sup(h, t)
+    return _mse(h_sup[:, :-1, :], h[:, 1:, :], group), h, h_sup
+
+
+def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
+    """TimeGANv1.py:475-503 -> d_loss.  Only the discriminator receives gradients."""
+    h = emb(x, t).detach()
+    h_hat = sup(h, t).detach()
+    e_hat = g(z, t).detach()
+    y_real, y_fake, y_fake_e = d(h, t), d(h_hat, t), d(e_hat, t)
+    d_loss_real = _bce_logits(y_real, True, group)
+    d_loss_fake = _bce_logits(y_fake, False, group)
+    d_loss_fake_e = _bce_logits(y_fake_e, False, group)
+    return d_loss_fake + d_loss_real + gamma * d_loss_fake_e
+
+
+def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None):
+    """TimeGANv1.py:506-553 -> g_loss.
+
+    The reference also evaluates rec(h) at :521 and overwrites the result at :528 before any use;
+    that forward contributes nothing to the loss or to any gradient and is not evaluated here.
+    """
+    h = emb(x, t)
+    h_sup = sup(h, t)
+    e_hat = g(z, t)
+    h_hat = sup(e_hat, t)
+    x_hat = rec(h_hat, t)
+    y_fake, y_fake_e = d(h_hat, t), d(e_hat, t)
+    g_loss_u = _bce_logits(y_fake, True, group)
+    g_loss_u_e = _bce_logits(y_fake_e, True, group)
+    g_loss_s = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
+    m_hat, s_hat = _batch_mean_std(x_hat, group)
+    m_x, s_x = _batch_mean_std(x, group)
+    # precedence exactly as written at TimeGANv1.py:543-544
+    g_loss_v1 = torch.mean(torch.abs((s_hat + 1e-6) - s_x + 1e-6))
+    g_loss_v2 = torch.mean(torch.abs(m_hat - m_x))
+    return g_loss_u + gamma * g_loss_u_e + 100 * torch.sqrt(g_loss_s) + 1000 * (g_loss_v1 + g_loss_v2)
+
+
+def inference(sup, g, rec, z, t):
+    """TimeGANv1.py:556-570: noise -> synthetic sequences."""
+    return rec(sup(g(z, t), t), t)

@@ -1,0 +1,163 @@
+"""The five TimeGAN networks, host-side mirrors of outdated_files/TimeGANv1.py:17-388.
+
+Same constructor contract (a nested cfg dict, config/config.yaml:1-38), same sub-module names and
+creation order (so state_dict keys, shapes and same-seed initial values match the reference and its
+`.pt` files interchange), same forward signature `forward(x, t)` with `t` the per-sequence lengths.
+
+Differences, all output-preserving:
+  * the recurrent layer is `timegan_amd.GRU` (HIP kernels) instead of torch.nn.GRU;
+  * pack_padded_sequence / pad_packed_sequence (TimeGANv1.py:56-65) are not materialised: lengths go
+    to the kernels, which skip finished sequences and write the padding rows themselves.
+
+`rnn_cls` exists so that the CPU tests and the CPU baseline can build the same networks on
+torch.nn.GRU; with it the forward takes the reference's literal pack -> GRU -> pad route.
+"""
+from typing import Dict, Sequence
+
+import torch
+import torch.nn as nn
+
+from .gru import GRU
+
+
+class _RecurrentBlock(nn.Module):
+    """Shared forward plumbing: [mlp] -> GRU over valid steps -> LayerNorm -> head."""
+
+    def _run_rnn(self, rnn: nn.Module, x: torch.Tensor, t) -> torch.Tensor:
+        if isinstance(rnn, GRU):
+            h, _ = rnn(x, lengths=t)
+            if self.padding_value != 0:
+                lens = torch.as_tensor([int(v) for v in t], device=x.device)
+                pad = torch.arange(self.seq_len, device=x.device)[None, :] >= lens[:, None]
+                h = h.masked_fill(pad[:, :, None], float(self.padding_value))
+            return h
+        packed = nn.utils.rnn.pack_padded_sequence(input=x, lengths=t, batch_first=True, enforce_sorted=True)
+        h, _ = rnn(packed)
+        h, _ = nn.utils.rnn.pad_packed_sequence(sequence=h, batch_first=True,
+                                                padding_value=self.padding_value, total_length=self.seq_len)
+        return h
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class Embedding(_RecurrentBlock):
+    """Encoder x -> H (TimeGANv1.py:17-74): mlp(F->H, LN, ReLU, H->H) -> GRU -> LN -> Linear."""
+
+    def __init__(self, cfg: Dict, rnn_cls=GRU):
+        super().__init__()
+        self.dim_features = int(cfg['emb']['dim_features'])
+        self.dim_hidden = int(cfg['emb']['dim_hidden'])
+        self.num_layers = int(cfg['emb']['num_layers'])
+        self.seq_len = int(cfg['system']['seq_len'])
+        self.padding_value = int(cfg['system']['padding_value'])
+        self.emb_rnn = rnn_cls(input_size=self.dim_hidden, hidden_size=self.dim_hidden,
+                               num_layers=self.num_layers, batch_first=True)
+        self.emb_linear = nn.Linear(self.dim_hidden, self.dim_hidden)
+        self.norm = nn.LayerNorm(self.dim_hidden)
+        self.mlp = nn.Sequential(nn.Linear(self.dim_features, self.dim_hidden), nn.LayerNorm(self.dim_hidden),
+                                 nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_hidden))
+
+    def forward(self, x: torch.Tensor, t) -> torch.Tensor:
+        h = self._run_rnn(self.emb_rnn, self.mlp(x), t)
+        return self.emb_linear(self.norm(h))
+
+
+class Recovery(_RecurrentBlock):
+    """Decoder H -> x (TimeGANv1.py:97-153): GRU -> LN -> mlp(H->H, LN, ReLU, H->F)."""
+
+    def __init__(self, cfg: Dict, rnn_cls=GRU):
+        super().__init__()
+        self.dim_output = int(cfg['rec']['dim_output'])
+        self.dim_hidden = int(cfg['rec']['dim_hidden'])
+        self.num_layers = int(cfg['rec']['num_layers'])
+        self.seq_len = int(cfg['system']['seq_len'])
+        self.padding_value = int(cfg['system']['padding_value'])
+        self.rec_rnn = rnn_cls(input_size=self.dim_hidden, hidden_size=self.dim_hidden,
+                               num_layers=self.num_layers, batch_first=True)
+        self.mlp = nn.Sequential(nn.Linear(self.dim_hidden, self.dim_hidden), nn.LayerNorm(self.dim_hidden),
+                                 nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_output))
+        self.norm = nn.LayerNorm(self.dim_hidden)
+
+    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
+        return self.mlp(self.norm(self._run_rnn(self.rec_rnn, h, t)))
+
+
+class Supervisor(_RecurrentBlock):
+    """Next-step predictor in latent space (TimeGANv1.py:176-232): GRU -> LN -> mlp(H->H, LN, ReLU, H->H)."""
+
+    def __init__(self, cfg: Dict, rnn_cls=GRU):
+        super().__init__()
+        self.dim_hidden = int(cfg['sup']['dim_hidden'])
+        self.num_layers = int(cfg['sup']['num_layers'])
+        self.seq_len = int(cfg['system']['seq_len'])
+        self.padding_value = int(cfg['system']['padding_value'])
+        self.sup_rnn = rnn_cls(input_size=self.dim_hidden, hidden_size=self.dim_hidden,
+                               num_layers=self.num_layers, batch_first=True)
+        self.mlp = nn.Sequential(nn.Linear(self.dim_hidden, self.dim_hidden), nn.LayerNorm(self.dim_hidden),
+                                 nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_hidden))
+        self.norm = nn.LayerNorm(self.dim_hidden)
+
+    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
+        return self.mlp(self.norm(self._run_rnn(self.sup_rnn, h, t)))
+
+
+class Generator(_RecurrentBlock):
+    """Noise z -> latent (TimeGANv1.py:254-311): mlp(F->2H, LN, ReLU, 2H->H) -> GRU -> LN -> Linear."""
+
+    def __init__(self, cfg: Dict, rnn_cls=GRU):
+        super().__init__()
+        self.dim_latent = int(cfg['g']['dim_latent'])
+        self.dim_hidden = int(cfg['g']['dim_hidden'])
+        self.num_layers = int(cfg['g']['num_layers'])
+        self.seq_len = int(cfg['system']['seq_len'])
+        self.padding_value = int(cfg['system']['padding_value'])
+        self.g_rnn = rnn_cls(input_size=self.dim_hidden, hidden_size=self.dim_hidden,
+                             num_layers=self.num_layers, batch_first=True)
+        self.g_linear = nn.Linear(self.dim_hidden, self.dim_hidden)
+        self.mlp = nn.Sequential(nn.Linear(self.dim_latent, self.dim_hidden * 2), nn.LayerNorm(self.dim_hidden * 2),
+                                 nn.ReLU(), nn.Linear(self.dim_hidden * 2, self.dim_hidden))
+        self.norm = nn.LayerNorm(self.dim_hidden)
+
+    def forward(self, z: torch.Tensor, t) -> torch.Tensor:
+        h = self._run_rnn(self.g_rnn, self.mlp(z), t)
+        return self.g_linear(self.norm(h))
+
+
+class Discriminator(_RecurrentBlock):
+    """Latent -> per-step logit (TimeGANv1.py:334-388): GRU -> LN -> Linear(H, 1); output (B, T, 1)."""
+
+    def __init__(self, cfg: Dict, rnn_cls=GRU):
+        super().__init__()
+        self.dim_hidden = int(cfg['d']['dim_hidden'])
+        self.num_layers = int(cfg['d']['num_layers'])
+        self.seq_len = int(cfg['system']['seq_len'])
+        self.padding_value = int(cfg['system']['padding_value'])
+        self.d_rnn = rnn_cls(input_size=self.dim_hidden, hidden_size=self.dim_hidden,
+                             num_layers=self.num_layers, batch_first=True)
+        self.norm = nn.LayerNorm(self.dim_hidden)
+        self.mlp = nn.Sequential(nn.Linear(self.dim_hidden, 1))
+
+    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
+        return self.mlp(self.norm(self._run_rnn(self.d_rnn, h, t)))
+
+
+def build_networks(cfg: Dict, rnn_cls=GRU) -> Dict[str, nn.Module]:
+    """The five networks in the reference's construction order (TimeGANv1.py:926-930)."""
+    return {"emb": Embedding(cfg, rnn_cls), "rec": Recovery(cfg, rnn_cls), "sup": Supervisor(cfg, rnn_cls),
+            "g": Generator(cfg, rnn_cls), "d": Discriminator(cfg, rnn_cls)}
+
+
+def make_cfg(features: int, hidden: int, layers: int, seq_len: int = 24, batch_size: int = 128,
+             lr: float = 1e-3, threshold: float = 0.15, device: str = "cuda:0") -> Dict:
+    """A cfg dict with the reference's schema (config/config.yaml:1-38)."""
+    return {
+        "system": {"seq_len": seq_len, "padding_value": 0.0, "lr": lr, "batch_size": batch_size,
+                   "device": device, "jointly_num_epochs": 1, "dataset": "synthetic"},
+        "emb": {"dim_features": features, "dim_hidden": hidden, "num_layers": layers, "num_epochs": 1},
+        "rec": {"dim_output": features, "dim_hidden": hidden, "num_layers": layers},
+        "sup": {"dim_hidden": hidden, "num_layers": layers, "num_epochs": 1},
+        "g": {"dim_latent": features, "dim_hidden": hidden, "num_layers": layers},
+        "d": {"dim_hidden": hidden, "num_layers": layers, "threshold": threshold},
+    }

@@ -1,0 +1,79 @@
+"""Data-parallel helpers: one process per GPU, batch-sharded, RCCL ("nccl" backend) over xGMI.
+
+The reference has no distributed code; this layer is new.  Convention used throughout: every rank
+evaluates the SAME global loss value, built from global statistics that are obtained with
+`dist_sum` (a differentiable all-reduce).  Each rank's backward then yields only the part of the
+gradient that flows through its own shard, so parameter gradients are combined with an all-reduce
+SUM (never an average) over one flat bucket per optimiser group.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+class _DistSum(torch.autograd.Function):
+    """S = sum over ranks of s_r.  Contract: every rank computes the SAME function of S afterwards
+    (replicated arithmetic only), so dL/ds_r = dL/dS is available locally and the backward is the
+    identity.  Feeding S into rank-specific arithmetic (e.g. subtracting it from local rows) breaks
+    that contract; rebuild such terms from all-reduced raw sums instead."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        out = x.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def dist_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    if world_size(group) == 1:
+        return x
+    return _DistSum.apply(x, group)
+
+
+def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
+    """Sum the gradients of `modules` over all ranks through ONE flat bucket.  Returns bucket size."""
+    if world_size(group) == 1:
+        return 0
+    params = [p for m in modules for p in m.parameters() if p.grad is not None]
+    if not params:
+        return 0
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    return int(flat.numel())
+
+
+def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:
+    if world_size(group) == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+def shard_batch(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Contiguous shard of a global batch for this rank (sizes differ by at most one)."""
+    w, r = world_size(group), rank(group)
+    if w == 1:
+        return x
+    n = x.shape[0]
+    base, rem = divmod(n, w)
+    start = r * base + min(r, rem)
+    return x[start:start + base + (1 if r < rem else 0)]
