@@ -1,0 +1,129 @@
+"""GPU tests of the nn.GRU drop-in module: PackedSequence in/out, autograd, sizes beyond the golden
+fixtures checked live against torch's CPU nn.GRU (a dependency present on the GPU box, not a
+reference file), and the shapes the reference's own smoke functions use."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import FWD_ATOL_SCALE, FWD_RTOL, GRAD_ATOL_SCALE, GRAD_RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(In, H, L, seed=0):
+    import timegan_amd as tg
+    torch.manual_seed(seed)
+    ref = nn.GRU(In, H, L, batch_first=True)
+    ours = tg.GRU(In, H, L, batch_first=True)
+    ours.load_state_dict(ref.state_dict())
+    return ref, ours.to("cuda:0")
+
+
+def _compare_run(ref, ours, x, lengths, packed, tag):
+    B, T, _ = x.shape
+    g = torch.Generator().manual_seed(1)
+    xr = x.clone().requires_grad_(True)
+    xo = x.clone().to("cuda:0").requires_grad_(True)
+    lens = [T] * B if lengths is None else lengths
+    pr = nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=True)
+    yr, hr = ref(pr)
+    yr, _ = nn.utils.rnn.pad_packed_sequence(yr, batch_first=True, padding_value=0, total_length=T)
+    if packed:
+        po = nn.utils.rnn.pack_padded_sequence(xo, lens, batch_first=True, enforce_sorted=True)
+        yo, ho = ours(po)
+        assert isinstance(yo, nn.utils.rnn.PackedSequence)
+        yo, _ = nn.utils.rnn.pad_packed_sequence(yo, batch_first=True, padding_value=0, total_length=T)
+    else:
+        yo, ho = ours(xo, lengths=lengths)
+    gy = torch.randn(yr.shape, generator=g)
+    gh = torch.randn(hr.shape, generator=g)
+    ((yr * gy).sum() + (hr * gh).sum()).backward()
+    ((yo * gy.cuda()).sum() + (ho * gh.cuda()).sum()).backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, f"{tag} y")
+    assert_close(ho.detach().cpu().numpy(), hr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, f"{tag} h_n")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} dx")
+    for (name, pr_), (_, po_) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert_close(po_.grad.cpu().numpy(), pr_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} d{name}")
+
+
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("B,T,In,H,L,lengths", [
+    (128, 24, 24, 24, 3, None),                       # C1/C2 stack
+    (9, 7, 6, 24, 2, [7, 7, 6, 4, 4, 3, 2, 1, 1]),    # ragged, In != H, whole-stack kernels
+    (64, 24, 96, 96, 3, None),                        # C3 stack (W_hh resident in LDS)
+    (20, 6, 28, 256, 1, None),                        # scorer shape: In 28 -> H 256, one layer
+    (17, 5, 100, 100, 2, [5, 5, 5, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1, 1, 1, 1]),   # H=100: odd tile count
+    (16, 4, 64, 512, 2, None),                        # C4 sizes, small batch (W_hh streamed from L2)
+])
+def test_dropin_module_matches_torch_cpu(B, T, In, H, L, lengths, packed):
+    ref, ours = _pair(In, H, L)
+    x = torch.rand(B, T, In, generator=torch.Generator().manual_seed(2))
+    _compare_run(ref, ours, x, lengths, packed, f"B{B}T{T}In{In}H{H}L{L}{'p' if packed else ''}")
+
+
+def test_same_module_called_three_times_in_one_graph():
+    """d(h), d(h_hat), d(e_hat) share weights inside one graph (TimeGANv1.py:493-495): saved state
+    must be per call."""
+    ref, ours = _pair(24, 24, 3, seed=4)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.rand(8, 24, 24, generator=g) for _ in range(3)]
+    lr = sum((ref(x)[0] ** 2).sum() for x in xs)
+    lo = sum((ours(x.cuda())[0] ** 2).sum() for x in xs)
+    lr.backward()
+    lo.backward()
+    for (name, pr_), (_, po_) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert_close(po_.grad.cpu().numpy(), pr_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, name)
+
+
+def test_no_grad_and_time_major_and_hx():
+    import timegan_amd as tg
+    torch.manual_seed(6)
+    ref = nn.GRU(12, 20, 2)                      # time-major, like metrics/GeneralRNN.py:41-44
+    ours = tg.GRU(12, 20, 2).to("cuda:0")
+    ours.load_state_dict(ref.state_dict())
+    x = torch.rand(9, 5, 12)
+    h0 = torch.randn(2, 5, 20)
+    with torch.no_grad():
+        yr, hr = ref(x, h0)
+        yo, ho = ours(x.cuda(), h0.cuda())
+    assert_close(yo.cpu().numpy(), yr.numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    assert_close(ho.cpu().numpy(), hr.numpy(), FWD_RTOL, FWD_ATOL_SCALE, "h_n")
+    # with gradients through hx
+    xr = x.clone().requires_grad_(True); hr0 = h0.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True); ho0 = h0.clone().cuda().requires_grad_(True)
+    (ref(xr, hr0)[0].sum() + ref(xr, hr0)[1].sum()).backward()
+    (ours(xo, ho0)[0].sum() + ours(xo, ho0)[1].sum()).backward()
+    assert_close(ho0.grad.cpu().numpy(), hr0.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dh0")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    for (name, pr_), (_, po_) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert_close(po_.grad.cpu().numpy(), pr_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, name)
+
+
+def test_reference_smoke_shapes_lengths_of_one_and_deep_stack():
+    """run_embedding_test (TimeGANv1.py:77-94): x (10,150,5), t = ones(10) as a FLOAT tensor,
+    H = 100, 50 layers -> (10,150,100); rows past length 1 are emb_linear(norm(0))."""
+    import timegan_amd as tg
+    cfg = tg.make_cfg(features=5, hidden=100, layers=50, seq_len=150, device="cuda:0")
+    torch.manual_seed(8)
+    cpu = tg.Embedding(cfg, rnn_cls=nn.GRU)
+    gpu = tg.Embedding(cfg).to("cuda:0")
+    gpu.load_state_dict(cpu.state_dict())
+    x = torch.randn(10, 150, 5)
+    t = torch.ones(10)
+    with torch.no_grad():
+        yr = cpu(x, t)
+        yo = gpu(x.cuda(), t)
+    assert tuple(yo.shape) == (10, 150, 100)
+    assert_close(yo.cpu().numpy(), yr.numpy(), FWD_RTOL, 1e-5, "embedding smoke")
+    pad_row = gpu.emb_linear(gpu.norm(torch.zeros(100, device="cuda:0")))
+    assert torch.allclose(yo[3, 77], pad_row, atol=1e-6)
+
+
+def test_unsorted_lengths_raise_like_torch():
+    import timegan_amd as tg
+    gru = tg.GRU(4, 8, 1, batch_first=True).to("cuda:0")
+    with pytest.raises(RuntimeError, match="sorted in decreasing order"):
+        gru(torch.zeros(3, 5, 4, device="cuda:0"), lengths=[2, 3, 5])
+    with pytest.raises(RuntimeError, match="greater than 0"):
+        gru(torch.zeros(3, 5, 4, device="cuda:0"), lengths=[3, 1, 0])
