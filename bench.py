@@ -95,6 +95,29 @@ def cpu_baseline(B, T, In, H, L, budget_s=20.0):
                        + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}" for r in results))}
 
 
+def joint_training_probe(tg, dev, features, H, L, T, B, group, iters=3):
+    """Secondary figure: eager 3-phase TimeGAN steps on the HIP GRU (TimeGANv1.py:573-812 loop bodies).
+    One joint iteration = 10 x (generator step + embedder step) + 1 discriminator step
+    = 116 GRU-stack forwards + 103 backwards plus the MLP / LayerNorm / Adam work around them."""
+    cfg = tg.make_cfg(features=features, hidden=H, layers=L, seq_len=T, device=str(dev))
+    torch.manual_seed(42)
+    tr = tg.TimeGANTrainer(cfg, device=dev, group=group)
+    x = torch.rand(B, T, features, device=dev)
+    out = {}
+    for name, fn, n in (("embedding", tr.embedding_step, 20), ("supervisor", tr.supervisor_step, 20),
+                        ("joint", tr.joint_step, iters)):
+        fn(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn(x)
+        torch.cuda.synchronize()
+        out[f"{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
+    out["note"] = ("eager PyTorch autograd around the HIP GRU, batch %d per GPU, %d features; "
+                   "host-launch bound at this size" % (B, features))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +126,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-joint", action="store_true", help="skip the secondary 3-phase training probe")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,9 +139,9 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
     import timegan_amd as tg
@@ -164,6 +189,10 @@ def main():
     dev_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
 
+    joint = None
+    if not args.no_joint and args.workload == "c2":
+        joint = joint_training_probe(tg, dev, 6, H, L, T, B, None if world == 1 else dist.group.WORLD)
+
     if rank == 0:
         flops, bytes_ = algorithmic_work(B, T, In, H, L)
         value = world * B * args.steps / elapsed
@@ -190,6 +219,8 @@ def main():
                        "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
             "roofline": roof,
         }
+        if joint is not None:
+            out["timegan_training"] = joint
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
         print(json.dumps(out), flush=True)
