@@ -138,11 +138,12 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
-        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+    # one GPU per rank; the modulo only matters when ranks are rehearsed on fewer GPUs (gloo backend)
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
+    if world > 1:
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     import timegan_amd as tg
 

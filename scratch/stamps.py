@@ -13,6 +13,6 @@ r = tg.GRURunner(B,T,In,H,L,tg.LAYOUT_TBF,dev); r.set_weights(w)
 for _ in range(50): r.forward(x); r.backward(dy)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong*128)()
-_lib.lib().tgru_debug_stamps.argtypes=[ctypes.c_void_p]; print('rc', _lib.lib().tgru_debug_stamps(out))
+_lib.lib().tgru_debug_stamps_h24.argtypes=[ctypes.c_void_p]; print('rc', _lib.lib().tgru_debug_stamps_h24(out))
 a = np.array(out[:]).reshape(16,8)[:6,:6]
 print('per wave cycles: [flush, lds-read/issue, mfma, elementwise, barrier, loop-top]'); print(a); print('per tick:', a.sum(1)/26)

@@ -89,13 +89,16 @@ def _compare(res, ref, tag):
             assert_close(a, b, GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} {name}_l{l}")
 
 
-@pytest.fixture(params=["auto", "per_layer"])
+@pytest.fixture(params=["auto", "small", "per_layer"])
 def kernel_path(request, monkeypatch):
-    """auto: whole-stack kernels when the shape allows; per_layer: force the per-layer kernels."""
+    """auto: the most specialised kernels the shape allows (H = 24: gru_h24.hip);
+    small: the general whole-stack kernels (gru_small.hip); per_layer: GEMM + recurrent kernels."""
+    monkeypatch.delenv("TGRU_FORCE_GENERIC", raising=False)
+    monkeypatch.delenv("TGRU_NO_H24", raising=False)
     if request.param == "per_layer":
         monkeypatch.setenv("TGRU_FORCE_GENERIC", "1")
-    else:
-        monkeypatch.delenv("TGRU_FORCE_GENERIC", raising=False)
+    elif request.param == "small":
+        monkeypatch.setenv("TGRU_NO_H24", "1")
     return request.param
 
 

@@ -19,6 +19,7 @@
 // gru_small_wgrad_kernel then turns the dg buffers into all weight and bias gradients of all
 // layers in a single launch (deterministic: fixed reduction order, no atomics).
 #include "tgru_internal.h"
+#include <stdlib.h>
 
 namespace tgru {
 
@@ -197,14 +198,18 @@ __global__ __launch_bounds__(MAXT) void gru_small_fwd_kernel(SmallFwdArgs a) {
         const int t = tick - l;
         const bool work = t >= 0 && t < T;
         STAMP(5);
+        // order matters for the memory counter: first take last tick's loads (everything older is
+        // long done), then issue this tick's stores and next tick's loads
+        float4 xin[2] = {xn[0], xn[1]};
+        if (l == 0) asm volatile("" : "+v"(xin[0].x), "+v"(xin[0].y), "+v"(xin[0].z), "+v"(xin[0].w),
+                                      "+v"(xin[1].x), "+v"(xin[1].y), "+v"(xin[1].z), "+v"(xin[1].w));
         if (pend) flush();
         STAMP(0);
         if (work) {
             const bool active = t < len;
             const float *hb = smem + (long)p * L * NT * 256;
-            float4 xin[2], hp[NT];
+            float4 hp[NT];
             if (l == 0) {
-                xin[0] = xn[0]; xin[1] = xn[1];
                 if (t + 1 < T) load_x(t + 1);
             } else {
 #pragma unroll
@@ -292,7 +297,13 @@ static hipError_t launch_fwd_t(const SmallFwdArgs &a, dim3 grid, dim3 block, siz
 
 static bool all_vec(int In, int H) { return (In & 3) == 0 && (H & 3) == 0; }
 
+static bool h24_shape(int In, int H) {
+    const char *e = getenv("TGRU_NO_H24");   // tests use this to reach the generic small-H kernels at H = 24
+    return H > 16 && H <= 24 && In <= 24 && !(e && e[0] == '1');
+}
+
 hipError_t launch_gru_small_fwd(const SmallFwdArgs &a, hipStream_t s) {
+    if (h24_shape(a.In, a.H)) return launch_gru_h24_fwd(a, s);
     const int NT = (a.H + 15) / 16;
     dim3 grid(gru_batch_blocks(a.B)), block(64 * NT * a.L);
     const size_t lds = (size_t)2 * a.L * NT * 1024;
@@ -529,6 +540,7 @@ static hipError_t launch_bwd_t(const SmallBwdArgs &a, dim3 grid, dim3 block, siz
 }
 
 hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s) {
+    if (h24_shape(a.In, a.H)) return launch_gru_h24_bwd(a, s);
     const int NT = (a.H + 15) / 16;
     dim3 grid(gru_batch_blocks(a.B)), block(64 * NT * a.L);
     const size_t lds = ((size_t)a.L * 4 * NT + (size_t)2 * a.L * NT) * 1024;

@@ -163,4 +163,8 @@ struct SmallWgradArgs {
 };
 hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s);
 
+// 16 < H <= 24, In <= 24 specialisation of the whole-stack kernels (gru_h24.hip)
+hipError_t launch_gru_h24_fwd(const SmallFwdArgs &a, hipStream_t s);
+hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s);
+
 }  // namespace tgru
