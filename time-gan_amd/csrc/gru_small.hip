@@ -16,8 +16,8 @@
 //     so memory latency hides behind the tick's MFMA chain instead of adding to it.
 //
 // The backward kernel mirrors this in reverse time / reverse layer order and also produces dx;
-// gru_small_wgrad_kernel then turns the dg buffers into all weight and bias gradients of all
-// layers in a single launch (deterministic: fixed reduction order, no atomics).
+// gru_wgrad.hip then turns the dg buffers into all weight and bias gradients of all layers
+// (deterministic: fixed reduction order, no atomics).
 #include "tgru_internal.h"
 #include <stdlib.h>
 
@@ -547,124 +547,6 @@ hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s) {
     const bool big = block.x > 512, vec = all_vec(a.In, a.H);
     if (NT == 1) return big ? launch_bwd_t<1, 1024>(a, grid, block, lds, vec, s) : launch_bwd_t<1, 512>(a, grid, block, lds, vec, s);
     return big ? launch_bwd_t<2, 1024>(a, grid, block, lds, vec, s) : launch_bwd_t<2, 512>(a, grid, block, lds, vec, s);
-}
-
-// ----------------------------------------------------------------------------------------------
-// weight gradients of all layers in one launch
-// ----------------------------------------------------------------------------------------------
-// One workgroup per 16x16 output tile of dW_ih / dW_hh (plus one per layer for the biases); its 16
-// waves split the T*B reduction rows, partial tiles are summed through LDS in a fixed order.
-//   dW_ih[m][n] = sum_k dg[k][m] * xin[k][n]                     m < 3H
-//   dW_hh[m][n] = sum_k dg[k][cm(m)] * h_{t-1}[k][n]             cm(m) = m < 2H ? m : m + H
-constexpr int kWgWaves = 16;
-
-__global__ __launch_bounds__(64 * kWgWaves) void gru_small_wgrad_kernel(SmallWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[kWgWaves][64][4];
-    const int H = a.H, B = a.B, T = a.T, L = a.L;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Mt = (3 * H + 15) / 16, NtH = (H + 15) / 16;
-    // decode the job
-    int job = blockIdx.x, l = 0, kind = -1, mt = 0, nt = 0;
-    for (l = 0; l < L; ++l) {
-        const int In_l = (l == 0) ? a.In : H;
-        const int nti = (In_l + 15) / 16;
-        const int n_ih = Mt * nti, n_hh = Mt * NtH;
-        if (job < n_ih) { kind = 0; mt = job / nti; nt = job % nti; break; }
-        job -= n_ih;
-        if (job < n_hh) { kind = 1; mt = job / NtH; nt = job % NtH; break; }
-        job -= n_hh;
-        if (job < 1) { kind = 2; break; }
-        job -= 1;
-    }
-    if (kind < 0) return;
-    if (kind == 2) {   // biases from the per-workgroup partial sums of the backward kernel
-        for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) {
-            float v = 0.f;
-            for (int k = 0; k < a.nblk; ++k) v += a.db_part[((long)k * L + l) * 4 * H + i];
-            if (i < 3 * H) {
-                a.db_ih[l][i] = a.accumulate ? a.db_ih[l][i] + v : v;
-                if (i < 2 * H) a.db_hh[l][i] = a.accumulate ? a.db_hh[l][i] + v : v;
-            } else {
-                a.db_hh[l][i - H] = a.accumulate ? a.db_hh[l][i - H] + v : v;
-            }
-        }
-        return;
-    }
-    const int In_l = (l == 0) ? a.In : H;
-    const int N = kind == 0 ? In_l : H;
-    const int K = T * B;
-    const int i = lane & 15, gq = lane >> 4;
-    const int m = 16 * mt + i;
-    const int acol = (kind == 1 && m >= 2 * H) ? m + H : m;
-    const bool mok = m < 3 * H;
-    const int n = 16 * nt + i;
-    const bool nok = n < N;
-    const float *dg = a.dg[l];
-    const float *src = kind == 0 ? (l == 0 ? a.x : a.y_int[l - 1]) : a.y_int[l];
-    const bool mapped = kind == 0 && l == 0 && a.xmap.mode != 0;
-    const int kchunk = ((K + kWgWaves - 1) / kWgWaves + 3) / 4 * 4;
-    const int kbeg = wave * kchunk, kend = min(K, kbeg + kchunk);
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
-        float av[16], bv[16];
-#pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const int k = k0 + 4 * s4 + gq;
-            av[s4] = 0.f; bv[s4] = 0.f;
-            if (k < kend) {
-                if (mok) av[s4] = dg[(long)k * 4 * H + acol];
-                if (nok) {
-                    if (kind == 0) {
-                        const long er = mapped ? map_row(a.xmap, k) : (long)k;
-                        if (er >= 0) bv[s4] = src[er * N + n];
-                    } else {
-                        if (k >= B) bv[s4] = src[(long)(k - B) * H + n];
-                        else if (a.h0) bv[s4] = a.h0[((long)l * B + k) * H + n];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 16; s4 += 2) {
-            acc0 = mf(av[s4], bv[s4], acc0);
-            acc1 = mf(av[s4 + 1], bv[s4 + 1], acc1);
-        }
-    }
-    mfma_drain();
-    *reinterpret_cast<float4 *>(&red[wave][lane][0]) =
-        make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
-    __syncthreads();
-    if (wave == 0) {
-        float4 s = *reinterpret_cast<const float4 *>(&red[0][lane][0]);
-        for (int w = 1; w < kWgWaves; ++w) {
-            const float4 v = *reinterpret_cast<const float4 *>(&red[w][lane][0]);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        // D: col = lane&15 (n), row = 4*(lane>>4) + reg (m)
-        float *out = kind == 0 ? a.dw_ih[l] : a.dw_hh[l];
-        const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mm = 16 * mt + 4 * gq + r;
-            if (mm < 3 * H && nok) {
-                float *dst = out + (long)mm * N + n;
-                *dst = a.accumulate ? *dst + sv[r] : sv[r];
-            }
-        }
-    }
-}
-
-hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
-    const int Mt = (3 * a.H + 15) / 16, NtH = (a.H + 15) / 16;
-    int jobs = 0;
-    for (int l = 0; l < a.L; ++l) {
-        const int In_l = l == 0 ? a.In : a.H;
-        jobs += Mt * ((In_l + 15) / 16) + Mt * NtH + 1;
-    }
-    hipLaunchKernelGGL(gru_small_wgrad_kernel, dim3(jobs), dim3(64 * kWgWaves), 0, s, a);
-    return hipGetLastError();
 }
 
 }  // namespace tgru

@@ -88,7 +88,12 @@ BwdWs bwd_ws(const Dims &d) {
     int ns3 = split_for(3 * d.H, d.In, (long)d.TB(), &kc);
     w.max_slabs = ns > ns2 ? ns : ns2;
     if (ns3 > w.max_slabs) w.max_slabs = ns3;
-    w.slabs = off; off += align64((size_t)w.max_slabs * 3 * d.H * widest);
+    size_t slab_floats = (size_t)w.max_slabs * 3 * d.H * widest;
+    if (small_shape) {
+        const size_t need = (size_t)small_wgrad_chunks(d.B, d.T) * small_wgrad_slab_floats(d.In, d.H, d.L);
+        if (need > slab_floats) slab_floats = need;
+    }
+    w.slabs = off; off += align64(slab_floats);
     w.total = off;
     return w;
 }
@@ -282,6 +287,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         TGRU_HIP(launch_gru_small_bwd(b, s));
         g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp; g.nblk = nblk;
         g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
+        g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(In, H, L); g.nchunks = small_wgrad_chunks(B, T);
         TGRU_HIP(launch_gru_small_wgrad(g, s));
         return TGRU_OK;
     }

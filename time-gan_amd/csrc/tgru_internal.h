@@ -159,9 +159,12 @@ struct SmallWgradArgs {
     const float *h0;
     const float *db_part; int nblk;
     float *dw_ih[kSmallMaxL], *dw_hh[kSmallMaxL], *db_ih[kSmallMaxL], *db_hh[kSmallMaxL];
+    float *slabs; long slab_stride; int nchunks;   // per-chunk partial gradients (workspace)
     int B, T, H, L, accumulate;
 };
 hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s);
+long small_wgrad_slab_floats(int In, int H, int L);
+int small_wgrad_chunks(int B, int T);
 
 // 16 < H <= 24, In <= 24 specialisation of the whole-stack kernels (gru_h24.hip)
 hipError_t launch_gru_h24_fwd(const SmallFwdArgs &a, hipStream_t s);
