@@ -205,6 +205,11 @@ def main():
             achieved = flops / (dev_ms_avg * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None}
+        tr_file = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
+        if os.path.exists(tr_file):     # HBM bytes per step from separate rocprofv3 --pmc passes of this command
+            with open(tr_file) as f:
+                roof["traffic"] = json.load(f)["hbm_bytes_per_step"]
+            roof["traffic_source"] = os.path.relpath(tr_file, ROOT)
         roof["kernel"] = "whole step: every kernel of one stack forward+backward (HIP events around the step)"
         roof["device_ms_per_step"] = round(dev_ms_avg, 4)
         roof["device_ms_median"] = round(dev_ms[len(dev_ms) // 2], 4)
