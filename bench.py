@@ -96,25 +96,29 @@ def cpu_baseline(B, T, In, H, L, budget_s=20.0):
 
 
 def joint_training_probe(tg, dev, features, H, L, T, B, group, iters=3):
-    """Secondary figure: eager 3-phase TimeGAN steps on the HIP GRU (TimeGANv1.py:573-812 loop bodies).
+    """Secondary figure: 3-phase TimeGAN steps on the HIP GRU (TimeGANv1.py:573-812 loop bodies).
     One joint iteration = 10 x (generator step + embedder step) + 1 discriminator step
-    = 116 GRU-stack forwards + 103 backwards plus the MLP / LayerNorm / Adam work around them."""
+    = 116 GRU-stack forwards + 103 backwards plus the MLP / LayerNorm / Adam work around them.
+    Measured eagerly and, on one GPU, with each optimiser sub-step replayed as a HIP graph."""
     cfg = tg.make_cfg(features=features, hidden=H, layers=L, seq_len=T, device=str(dev))
-    torch.manual_seed(42)
-    tr = tg.TimeGANTrainer(cfg, device=dev, group=group)
     x = torch.rand(B, T, features, device=dev)
     out = {}
-    for name, fn, n in (("embedding", tr.embedding_step, 20), ("supervisor", tr.supervisor_step, 20),
-                        ("joint", tr.joint_step, iters)):
-        fn(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn(x)
-        torch.cuda.synchronize()
-        out[f"{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
-    out["note"] = ("eager PyTorch autograd around the HIP GRU, batch %d per GPU, %d features; "
-                   "host-launch bound at this size" % (B, features))
+    modes = [("", False)] + ([("hipgraph_", True)] if group is None else [])
+    for prefix, graphs in modes:
+        torch.manual_seed(42)
+        tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs)
+        for name, fn, n in (("embedding", tr.embedding_step, 20), ("supervisor", tr.supervisor_step, 20),
+                            ("joint", tr.joint_step, iters * (4 if graphs else 1))):
+            for _ in range(3):
+                fn(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn(x)
+            torch.cuda.synchronize()
+            out[f"{prefix}{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
+    out["note"] = ("PyTorch autograd around the HIP GRU, batch %d per GPU, %d features; the eager figures "
+                   "are host-launch bound at this size" % (B, features))
     return out
 
 

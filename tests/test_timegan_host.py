@@ -115,12 +115,13 @@ def _losses(device, on_gpu):
     assert_close(xh.cpu().numpy(), d["inference.x_hat"], 1e-5, 2e-6, "inference.x_hat")
 
 
-def _steps(device, on_gpu):
+def _steps(device, on_gpu, use_graphs=False):
     """embedding x3, supervisor x3, joint x2 (D steps), joint x1 with a high threshold (D skipped)."""
     import timegan_amd as tg
     d = np.load(os.path.join(GOLDEN, "steps_c1.npz"))
     kw = {} if on_gpu else {"rnn_cls": torch.nn.GRU}
-    tr = tg.TimeGANTrainer(_cfg(), device=device, **kw)
+    tr = tg.TimeGANTrainer(_cfg(), device=device, use_graphs=use_graphs, **kw)
+    assert tr.use_graphs == use_graphs
     _load_sd(d, "init.", tr.nets, device)
 
     def check_params(tag, rtol, atol_abs):
@@ -180,3 +181,9 @@ def test_losses_match_reference_gpu():
 @pytest.mark.gpu
 def test_training_steps_match_reference_gpu():
     _steps(torch.device("cuda:0"), True)
+
+
+@pytest.mark.gpu
+def test_training_steps_hip_graphs_match_reference_gpu():
+    """Same fixture with every optimiser sub-step captured into a HIP graph after two eager calls."""
+    _steps(torch.device("cuda:0"), True, use_graphs=True)

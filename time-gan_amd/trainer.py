@@ -15,6 +15,87 @@ from .modules import build_networks
 from .parallel import all_reduce_grads, broadcast_parameters, world_size
 
 
+class _GraphedStep:
+    """Runs `fn(*tensors) -> tuple of tensors` eagerly for the first `warmup` calls (they are real
+    steps), then captures it once into a HIP graph and replays it: one graph launch instead of
+    hundreds of kernel launches.  Inputs are copied into static buffers; outputs are static tensors.
+    A call with different shapes (a ragged last batch) runs eagerly."""
+
+    def __init__(self, fn, warmup: int = 2):
+        self.fn, self.warmup, self.calls = fn, warmup, 0
+        self.graph, self.static_in, self.static_out, self.shapes = None, None, None, None
+
+    def __call__(self, *tensors):
+        shapes = tuple(tuple(t.shape) for t in tensors)
+        if self.calls < self.warmup or (self.shapes is not None and shapes != self.shapes):
+            self.calls += 1
+            return self.fn(*tensors)
+        if self.graph is None:
+            self.shapes = shapes
+            self.static_in = [t.clone() for t in tensors]
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.fn(*self.static_in)
+        for s, t in zip(self.static_in, tensors):
+            s.copy_(t)
+        self.graph.replay()
+        return self.static_out
+
+
+class _GraphedDiscriminatorStep:
+    """Discriminator sub-step in graph mode: one graph holds zero_grad + forward + backward, a second
+    one the Adam update, replayed only when the loss exceeds the threshold (TimeGANv1.py:806-808).
+    Both are captured back to back so the update graph reads the gradient buffers the first one
+    writes; eager calls (warm-up, other shapes) run both halves eagerly for the same reason."""
+
+    def __init__(self, fwd_bwd, opt_step, threshold_of, warmup: int = 2):
+        self.fwd_bwd, self.opt_step, self.threshold_of = fwd_bwd, opt_step, threshold_of
+        self.warmup, self.calls = warmup, 0
+        self.g_fb, self.g_step, self.static_in, self.static_out, self.shapes = None, None, None, None, None
+
+    def __call__(self, x, z):
+        shapes = (tuple(x.shape), tuple(z.shape))
+        if self.calls < self.warmup or (self.shapes is not None and shapes != self.shapes):
+            self.calls += 1
+            (d_loss,) = self.fwd_bwd(x, z)
+            stepped = bool(d_loss > self.threshold_of())
+            if stepped:
+                self.opt_step()
+            return d_loss, stepped
+        if self.g_fb is None:
+            self.shapes = shapes
+            self.static_in = [x.clone(), z.clone()]
+            torch.cuda.synchronize()
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self.static_out = self.fwd_bwd(*self.static_in)
+            self.g_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_step):
+                self.opt_step()
+        self.static_in[0].copy_(x)
+        self.static_in[1].copy_(z)
+        self.g_fb.replay()
+        d_loss = self.static_out[0]
+        stepped = bool(d_loss > self.threshold_of())
+        if stepped:
+            self.g_step.replay()
+        return d_loss, stepped
+
+
+def _init_adam_state(opt):
+    """Creates Adam's per-parameter state now instead of inside the first step(): a step captured
+    into a graph must not contain the zero-initialisation of its own moment estimates."""
+    for group in opt.param_groups:
+        saved = [p.grad for p in group["params"]]
+        for p in group["params"]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        opt._init_group(group, [], [], [], [], [], [])
+        for p, g in zip(group["params"], saved):
+            p.grad = g
+
+
 class TimeGANTrainer:
     """Owns the five networks and the six Adam optimisers of TimeGANv1.py:926-938.
 
@@ -22,7 +103,7 @@ class TimeGANTrainer:
     (`emb_opt_side` / `emb_opt_main`, TimeGANv1.py:933-934), each with its own moment estimates.
     """
 
-    def __init__(self, cfg: Dict, device=None, rnn_cls=None, group=None, nets=None):
+    def __init__(self, cfg: Dict, device=None, rnn_cls=None, group=None, nets=None, use_graphs: bool = False):
         self.cfg = cfg
         self.device = torch.device(device if device is not None else cfg["system"]["device"])
         kw = {} if rnn_cls is None else {"rnn_cls": rnn_cls}
@@ -33,11 +114,25 @@ class TimeGANTrainer:
         broadcast_parameters(self.nets.values(), group=group)
         lr = float(cfg["system"]["lr"])
         n = self.nets
-        self.opt = {"emb_side": Adam(n["emb"].parameters(), lr=lr), "emb_main": Adam(n["emb"].parameters(), lr=lr),
-                    "rec": Adam(n["rec"].parameters(), lr=lr), "sup": Adam(n["sup"].parameters(), lr=lr),
-                    "g": Adam(n["g"].parameters(), lr=lr), "d": Adam(n["d"].parameters(), lr=lr)}
+        # HIP-graph mode: every optimiser sub-step (zero_grad + forward + backward + Adam) is one
+        # captured graph.  Single process only: the gradient all-reduce is not captured.
+        self.use_graphs = bool(use_graphs) and world_size(group) == 1 and self.device.type == "cuda"
+        kw_opt = {"capturable": True} if self.use_graphs else {}
+        self.opt = {"emb_side": Adam(n["emb"].parameters(), lr=lr, **kw_opt),
+                    "emb_main": Adam(n["emb"].parameters(), lr=lr, **kw_opt),
+                    "rec": Adam(n["rec"].parameters(), lr=lr, **kw_opt), "sup": Adam(n["sup"].parameters(), lr=lr, **kw_opt),
+                    "g": Adam(n["g"].parameters(), lr=lr, **kw_opt), "d": Adam(n["d"].parameters(), lr=lr, **kw_opt)}
         self.d_threshold = float(cfg["d"]["threshold"])
         self.seq_len = int(cfg["system"]["seq_len"])
+        if self.use_graphs:
+            self._g_emb = _GraphedStep(self._embedding_core)
+            self._g_sup = _GraphedStep(self._supervisor_core)
+            self._g_gen = _GraphedStep(self._joint_g_core)
+            self._g_e = _GraphedStep(self._joint_e_core)
+            self._g_d = _GraphedDiscriminatorStep(self._joint_d_fwd_bwd_core, self.opt["d"].step,
+                                                  lambda: self.d_threshold)
+            for o in self.opt.values():
+                _init_adam_state(o)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _zero(self, *names):
@@ -51,10 +146,65 @@ class TimeGANTrainer:
         """What Energy.extract_time returns for a batch (data/Energy.py:12-19): every length = T."""
         return [x.shape[1]] * x.shape[0]
 
+    # -- sub-step cores: tensors in, loss tensors out, no host synchronisation ------------------------
+    def _embedding_core(self, x):
+        n = self.nets
+        self._zero("emb", "rec", "sup")
+        e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, self.lengths_of(x), group=self.group)
+        e_loss0.backward()
+        self._sync_grads("emb", "rec")
+        self.opt["emb_side"].step()
+        self.opt["rec"].step()
+        return (e_loss0.detach(),)
+
+    def _supervisor_core(self, x):
+        n = self.nets
+        self._zero("emb", "sup")
+        s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
+        s_loss.backward()
+        self._sync_grads("sup")
+        self.opt["sup"].step()
+        return (s_loss.detach(),)
+
+    def _joint_g_core(self, x, z):
+        n = self.nets
+        self._zero("emb", "rec", "sup", "g", "d")
+        g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
+                                          group=self.group)
+        g_loss.backward()
+        self._sync_grads("g", "sup")
+        self.opt["g"].step()
+        self.opt["sup"].step()
+        return (g_loss.detach(),)
+
+    def _joint_e_core(self, x):
+        n = self.nets
+        self._zero("emb", "rec", "sup")
+        e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
+                                                     group=self.group)
+        e_loss.backward()
+        self._sync_grads("emb", "rec")
+        self.opt["emb_main"].step()
+        self.opt["rec"].step()
+        return (e_loss.detach(),)
+
+    def _joint_d_fwd_bwd_core(self, x, z):
+        """Graph mode only: forward AND backward of the discriminator loss; whether the optimiser
+        steps is decided on the host afterwards (an unused backward changes nothing: the
+        gradients are zeroed before their next use, TimeGANv1.py:765-769,796-799)."""
+        n = self.nets
+        self._zero("emb", "sup", "g", "d")
+        d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
+                                              group=self.group)
+        d_loss.backward()
+        return (d_loss.detach(),)
+
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
     def embedding_step(self, x: torch.Tensor, t=None) -> float:
+        if t is None:
+            (loss,) = (self._g_emb if self.use_graphs else self._embedding_core)(x)
+            return float(loss)
         n = self.nets
-        t = self.lengths_of(x) if t is None else t
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, t, group=self.group)
         e_loss0.backward()
@@ -65,8 +215,10 @@ class TimeGANTrainer:
 
     # -- phase 2: supervisor (TimeGANv1.py:662-683) -------------------------------------------------
     def supervisor_step(self, x: torch.Tensor, t=None) -> float:
+        if t is None:
+            (loss,) = (self._g_sup if self.use_graphs else self._supervisor_core)(x)
+            return float(loss)
         n = self.nets
-        t = self.lengths_of(x) if t is None else t
         self._zero("emb", "sup")
         s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
         s_loss.backward()
@@ -81,8 +233,35 @@ class TimeGANTrainer:
         `noise`: optional 11 tensors shaped like x used in place of torch.rand_like(x)
         (TimeGANv1.py:762,793), so runs can be reproduced exactly.
         """
+        if t is not None:
+            return self._joint_step_with_lengths(x, t, noise)
+        noise = list(noise) if noise is not None else None
+        g_losses, e_losses = [], []
+        for _ in range(10):
+            z = noise.pop(0) if noise is not None else torch.rand_like(x)
+            (g_loss,) = (self._g_gen if self.use_graphs else self._joint_g_core)(x, z)
+            g_losses.append(g_loss.clone() if self.use_graphs else g_loss)
+            (e_loss,) = (self._g_e if self.use_graphs else self._joint_e_core)(x)
+            e_losses.append(e_loss.clone() if self.use_graphs else e_loss)
+        z = noise.pop(0) if noise is not None else torch.rand_like(x)
+        if self.use_graphs:
+            d_loss, stepped = self._g_d(x, z)
+        else:
+            n = self.nets
+            self._zero("emb", "sup", "g", "d")
+            d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
+                                                  group=self.group)
+            stepped = bool(d_loss > self.d_threshold)
+            if stepped:
+                d_loss.backward()
+                self._sync_grads("d")
+                self.opt["d"].step()
+        return {"g_loss": [float(v) for v in torch.stack(g_losses).tolist()],
+                "e_loss": [float(v) for v in torch.stack(e_losses).tolist()],
+                "d_loss": float(d_loss.detach()), "d_stepped": stepped}
+
+    def _joint_step_with_lengths(self, x, t, noise):
         n = self.nets
-        t = self.lengths_of(x) if t is None else t
         noise = list(noise) if noise is not None else None
         out = {"g_loss": [], "e_loss": []}
         for _ in range(10):
@@ -95,7 +274,6 @@ class TimeGANTrainer:
             self._sync_grads("g", "sup")
             self.opt["g"].step()
             self.opt["sup"].step()
-
             self._zero("emb", "rec", "sup")
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
             e_loss.backward()
@@ -103,11 +281,9 @@ class TimeGANTrainer:
             self._sync_grads("emb", "rec")
             self.opt["emb_main"].step()
             self.opt["rec"].step()
-
         z = noise.pop(0) if noise is not None else torch.rand_like(x)
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z, group=self.group)
-        # the loss value is global (identical on every rank), so all ranks take the same branch
         stepped = bool(d_loss > self.d_threshold)
         if stepped:
             d_loss.backward()
