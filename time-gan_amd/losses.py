@@ -50,6 +50,20 @@ def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Te
     return c + m1, torch.sqrt(torch.clamp(m2 - m1 * m1, min=0.0))
 
 
+def _apply_batched(net, inputs, t):
+    """net(u, t) for each u in `inputs`, evaluated as ONE call on the concatenated batch when every
+    sequence has full length (rows of a batch never interact inside a network, so the results are
+    those of the separate calls the reference makes, e.g. d(h), d(_h), d(_e) at TimeGANv1.py:493-495;
+    the weight gradients come out already summed).  Ragged lengths keep separate calls, because a
+    concatenation of sorted length lists is not sorted."""
+    T = inputs[0].shape[1]
+    lens = [int(v) for v in t]
+    if len(inputs) == 1 or any(v != T for v in lens):
+        return [net(u, t) for u in inputs]
+    out = net(torch.cat(inputs, dim=0), lens * len(inputs))
+    return out.split([u.shape[0] for u in inputs], dim=0)
+
+
 def embedding_forward_side(emb, rec, x, t, group=None):
     """TimeGANv1.py:410-423 -> (e_loss0, x_tilde)."""
     h = emb(x, t)
@@ -78,10 +92,11 @@ def supervisor_forward(emb, sup, x, t, group=None):
 
 def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
     """TimeGANv1.py:475-503 -> d_loss.  Only the discriminator receives gradients."""
-    h = emb(x, t).detach()
-    h_hat = sup(h, t).detach()
-    e_hat = g(z, t).detach()
-    y_real, y_fake, y_fake_e = d(h, t), d(h_hat, t), d(e_hat, t)
+    with torch.no_grad():   # the reference detaches all three (TimeGANv1.py:486-491): nothing to save for backward
+        h = emb(x, t)
+        h_hat = sup(h, t)
+        e_hat = g(z, t)
+    y_real, y_fake, y_fake_e = _apply_batched(d, [h, h_hat, e_hat], t)
     d_loss_real = _bce_logits(y_real, True, group)
     d_loss_fake = _bce_logits(y_fake, False, group)
     d_loss_fake_e = _bce_logits(y_fake_e, False, group)
@@ -95,11 +110,10 @@ def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None):
     that forward contributes nothing to the loss or to any gradient and is not evaluated here.
     """
     h = emb(x, t)
-    h_sup = sup(h, t)
     e_hat = g(z, t)
-    h_hat = sup(e_hat, t)
+    h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
     x_hat = rec(h_hat, t)
-    y_fake, y_fake_e = d(h_hat, t), d(e_hat, t)
+    y_fake, y_fake_e = _apply_batched(d, [h_hat, e_hat], t)
     g_loss_u = _bce_logits(y_fake, True, group)
     g_loss_u_e = _bce_logits(y_fake_e, True, group)
     g_loss_s = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)

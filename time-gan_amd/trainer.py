@@ -117,7 +117,12 @@ class TimeGANTrainer:
         # HIP-graph mode: every optimiser sub-step (zero_grad + forward + backward + Adam) is one
         # captured graph.  Single process only: the gradient all-reduce is not captured.
         self.use_graphs = bool(use_graphs) and world_size(group) == 1 and self.device.type == "cuda"
-        kw_opt = {"capturable": True} if self.use_graphs else {}
+        # On the GPU each Adam update is one fused multi-tensor kernel (torch's default foreach path
+        # issues a dozen launches per update, plus one per parameter for the bias corrections when
+        # the step counters live on the device, as graph capture needs them to).
+        kw_opt = {"fused": True} if self.device.type == "cuda" else {}
+        if self.use_graphs:
+            kw_opt["capturable"] = True
         self.opt = {"emb_side": Adam(n["emb"].parameters(), lr=lr, **kw_opt),
                     "emb_main": Adam(n["emb"].parameters(), lr=lr, **kw_opt),
                     "rec": Adam(n["rec"].parameters(), lr=lr, **kw_opt), "sup": Adam(n["sup"].parameters(), lr=lr, **kw_opt),
