@@ -89,15 +89,20 @@ def _compare(res, ref, tag):
             assert_close(a, b, GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} {name}_l{l}")
 
 
-@pytest.fixture(params=["auto", "small", "per_layer"])
+@pytest.fixture(params=["auto", "h24", "small", "per_layer"])
 def kernel_path(request, monkeypatch):
-    """auto: the most specialised kernels the shape allows (H = 24: gru_h24.hip);
-    small: the general whole-stack kernels (gru_small.hip); per_layer: GEMM + recurrent kernels."""
-    monkeypatch.delenv("TGRU_FORCE_GENERIC", raising=False)
-    monkeypatch.delenv("TGRU_NO_H24", raising=False)
+    """auto: the kernels the library picks for the shape (H, In <= 32: one sequence per workgroup,
+    gru_vec.hip); h24: the MFMA whole-stack kernels specialised for H = 24 (gru_h24.hip), which the
+    library itself picks above 2048 sequences; small: the general MFMA whole-stack kernels
+    (gru_small.hip); per_layer: GEMM + recurrent kernels."""
+    for k in ("TGRU_FORCE_GENERIC", "TGRU_NO_H24", "TGRU_NO_VEC"):
+        monkeypatch.delenv(k, raising=False)
     if request.param == "per_layer":
         monkeypatch.setenv("TGRU_FORCE_GENERIC", "1")
+    elif request.param == "h24":
+        monkeypatch.setenv("TGRU_NO_VEC", "1")
     elif request.param == "small":
+        monkeypatch.setenv("TGRU_NO_VEC", "1")
         monkeypatch.setenv("TGRU_NO_H24", "1")
     return request.param
 

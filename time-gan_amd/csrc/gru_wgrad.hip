@@ -181,6 +181,10 @@ hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gru_wgrad_partial_kernel, dim3(a.nchunks, a.L), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    return launch_gru_small_wgrad_reduce(a, s);
+}
+
+hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, hipStream_t s) {
     const long items = a.slab_stride + (long)a.L * 4 * a.H;
     hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

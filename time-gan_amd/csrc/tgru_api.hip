@@ -36,6 +36,14 @@ bool use_small(int In, int H, int L) {
     return !(e && e[0] == '1');
 }
 
+// Small stacks with up to 2048 sequences run one sequence per workgroup on the vector ALU
+// (gru_vec.hip); TGRU_NO_VEC=1 selects the MFMA whole-stack kernels for them instead.
+bool use_vec(int B, int T, int In, int H, int L) {
+    if (!use_small(In, H, L) || !gru_vec_supported(B, T, In, H, L)) return false;
+    const char *e = getenv("TGRU_NO_VEC");
+    return !(e && e[0] == '1');
+}
+
 // reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
 size_t reserve_floats(const Dims &d) {
     size_t n = (size_t)d.L * 4 * align64(d.TBH());
@@ -80,7 +88,10 @@ BwdWs bwd_ws(const Dims &d) {
     w.dg = off; off += (small_shape ? (size_t)d.L : 1) * align64(d.TB() * 4 * d.H);
     w.dyb = off; off += 2 * align64(d.TB() * (size_t)(d.H > d.In ? d.H : d.In));
     w.wtp = off; off += align64(packed_whh_floats(d.H));
-    w.dbp = off; off += align64((size_t)gru_batch_blocks(d.B) * 4 * d.H * (small_shape ? d.L : 1));
+    size_t nblk = (size_t)gru_batch_blocks(d.B);
+    const bool vec_shape = gru_vec_supported(d.B, d.T, d.In, d.H, d.L);
+    if (vec_shape && (size_t)gru_vec_workgroups(d.B) > nblk) nblk = (size_t)gru_vec_workgroups(d.B);
+    w.dbp = off; off += align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
     int ns = split_for(3 * d.H, widest, (long)d.TB(), &kc);
@@ -91,6 +102,10 @@ BwdWs bwd_ws(const Dims &d) {
     size_t slab_floats = (size_t)w.max_slabs * 3 * d.H * widest;
     if (small_shape) {
         const size_t need = (size_t)small_wgrad_chunks(d.B, d.T) * small_wgrad_slab_floats(d.In, d.H, d.L);
+        if (need > slab_floats) slab_floats = need;
+    }
+    if (vec_shape) {
+        const size_t need = (size_t)gru_vec_workgroups(d.B) * small_wgrad_slab_floats(d.In, d.H, d.L);
         if (need > slab_floats) slab_floats = need;
     }
     w.slabs = off; off += align64(slab_floats);
@@ -200,7 +215,8 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         }
         f.h0 = h0; f.y_ext = y; f.ymap = ext_map(d, toff); f.h_n = h_n; f.lengths = lengths;
         f.B = B; f.T = T; f.H = H; f.L = L;
-        TGRU_HIP(launch_gru_small_fwd(f, s));
+        if (use_vec(B, T, In, H, L)) TGRU_HIP(launch_gru_vec_fwd(f, s));
+        else TGRU_HIP(launch_gru_small_fwd(f, s));
         return TGRU_OK;
     }
 
@@ -284,6 +300,17 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         b.dy_ext = dy; b.dymap = ext_map(d, toff); b.dh_n = dh_n; b.h0 = h0;
         b.dx_ext = dx; b.dxmap = ext_map(d, toff); b.In = In; b.dh0 = dh0; b.db_part = dbp;
         b.lengths = lengths; b.B = B; b.T = T; b.H = H; b.L = L;
+        g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp;
+        g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
+        g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(In, H, L);
+        if (use_vec(B, T, In, H, L)) {
+            // the backward kernel accumulates the weight gradients itself: one partial per workgroup
+            b.x = x; b.xmap = ext_map(d, toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
+            TGRU_HIP(launch_gru_vec_bwd(b, s));
+            g.nblk = gru_vec_workgroups(B); g.nchunks = g.nblk;
+            TGRU_HIP(launch_gru_small_wgrad_reduce(g, s));
+            return TGRU_OK;
+        }
         TGRU_HIP(launch_gru_small_bwd(b, s));
         g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp; g.nblk = nblk;
         g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;

@@ -149,6 +149,10 @@ struct SmallBwdArgs {
     float *db_part;                // (nblk, L, 4H)
     const int *lengths;
     int B, T, H, L;
+    // one-sequence-per-workgroup kernels only (gru_vec.hip): layer-0 input and the per-workgroup
+    // partial weight gradients
+    const float *x; RowMap xmap;
+    float *slabs; long slab_stride;
 };
 hipError_t launch_gru_small_bwd(const SmallBwdArgs &a, hipStream_t s);
 
@@ -163,11 +167,19 @@ struct SmallWgradArgs {
     int B, T, H, L, accumulate;
 };
 hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s);
+hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, hipStream_t s);   // stage 2 alone
 long small_wgrad_slab_floats(int In, int H, int L);
 int small_wgrad_chunks(int B, int T);
 
 // 16 < H <= 24, In <= 24 specialisation of the whole-stack kernels (gru_h24.hip)
 hipError_t launch_gru_h24_fwd(const SmallFwdArgs &a, hipStream_t s);
 hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s);
+
+// H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
+// leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
+hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s);
+hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, hipStream_t s);
+int gru_vec_workgroups(int B);
+bool gru_vec_supported(int B, int T, int In, int H, int L);
 
 }  // namespace tgru

@@ -50,6 +50,27 @@ def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Te
     return c + m1, torch.sqrt(torch.clamp(m2 - m1 * m1, min=0.0))
 
 
+def _fork_join(fns, streams):
+    """Evaluates independent callables; with `streams` (side HIP streams, used while a sub-step is
+    captured into a graph) the second and later ones run on their own stream between a fork and a
+    join on the current stream, so independent networks become parallel branches of the graph.
+    Autograd replays each branch's backward on the stream its forward ran on."""
+    if not streams or len(fns) == 1:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    outs = [None] * len(fns)
+    side = list(streams[:len(fns) - 1])
+    for s in side:
+        s.wait_stream(cur)
+    outs[0] = fns[0]()
+    for i, s in enumerate(side):
+        with torch.cuda.stream(s):
+            outs[i + 1] = fns[i + 1]()
+    for s in side:
+        cur.wait_stream(s)
+    return outs
+
+
 def _apply_batched(net, inputs, t):
     """net(u, t) for each u in `inputs`, evaluated as ONE call on the concatenated batch when every
     sequence has full length (rows of a batch never interact inside a network, so the results are
@@ -72,11 +93,10 @@ def embedding_forward_side(emb, rec, x, t, group=None):
     return 10 * torch.sqrt(e_loss_t0), x_tilde
 
 
-def embedding_forward_main(emb, sup, rec, x, t, group=None):
+def embedding_forward_main(emb, sup, rec, x, t, group=None, streams=None):
     """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0)."""
     h = emb(x, t)
-    x_tilde = rec(h, t)
-    h_sup = sup(h, t)
+    x_tilde, h_sup = _fork_join([lambda: rec(h, t), lambda: sup(h, t)], streams)
     g_loss_sup = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
     e_loss_t0 = _mse(x_tilde, x, group)
     e_loss0 = 10 * torch.sqrt(e_loss_t0)
@@ -90,12 +110,13 @@ def supervisor_forward(emb, sup, x, t, group=None):
     return _mse(h_sup[:, :-1, :], h[:, 1:, :], group), h, h_sup
 
 
-def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
+def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None, streams=None):
     """TimeGANv1.py:475-503 -> d_loss.  Only the discriminator receives gradients."""
     with torch.no_grad():   # the reference detaches all three (TimeGANv1.py:486-491): nothing to save for backward
-        h = emb(x, t)
-        h_hat = sup(h, t)
-        e_hat = g(z, t)
+        def real_branch():
+            h_ = emb(x, t)
+            return h_, sup(h_, t)
+        (h, h_hat), e_hat = _fork_join([real_branch, lambda: g(z, t)], streams)
     y_real, y_fake, y_fake_e = _apply_batched(d, [h, h_hat, e_hat], t)
     d_loss_real = _bce_logits(y_real, True, group)
     d_loss_fake = _bce_logits(y_fake, False, group)
@@ -103,17 +124,16 @@ def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
     return d_loss_fake + d_loss_real + gamma * d_loss_fake_e
 
 
-def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None):
+def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None, streams=None):
     """TimeGANv1.py:506-553 -> g_loss.
 
     The reference also evaluates rec(h) at :521 and overwrites the result at :528 before any use;
     that forward contributes nothing to the loss or to any gradient and is not evaluated here.
     """
-    h = emb(x, t)
-    e_hat = g(z, t)
+    h, e_hat = _fork_join([lambda: emb(x, t), lambda: g(z, t)], streams)
     h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
-    x_hat = rec(h_hat, t)
-    y_fake, y_fake_e = _apply_batched(d, [h_hat, e_hat], t)
+    x_hat, (y_fake, y_fake_e) = _fork_join([lambda: rec(h_hat, t),
+                                            lambda: _apply_batched(d, [h_hat, e_hat], t)], streams)
     g_loss_u = _bce_logits(y_fake, True, group)
     g_loss_u_e = _bce_logits(y_fake_e, True, group)
     g_loss_s = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
