@@ -8,15 +8,24 @@
 // and step (36 packed FMAs per lane).  The time step, which is what bounds a recurrence this small,
 // becomes several times shorter.  Above a few thousand sequences the MFMA kernels win again.
 //
-// Layout of one workgroup: one wave per layer (layers run as a wavefront: wave l works on time step
-// tick - l).  In a wave, lane = (p, j): j = lane & 31 is a hidden unit (forward) or an input /
-// hidden column (backward), p = lane >> 5 selects the half of the work:
+// Layout of one workgroup: one COMPUTE wave per layer (layers run as a wavefront: wave l works on
+// time step tick - l) plus one LOADER wave.  In a compute wave, lane = (p, j): j = lane & 31 is a
+// hidden unit (forward) or an input / hidden column (backward), p = lane >> 5 selects the half of
+// the work:
 //   forward   p = 0: rows j of W_ir, W_iz, W_in times the layer input x_t
 //             p = 1: rows j of W_hr, W_hz, W_hn times h_{t-1}
 //   backward  p = 0: column j of W_ih (dx_t[j]);  p = 1: column j of W_hh (dh_{t-1}[j])
 // Weights stay in VGPRs for the whole kernel; the vectors they multiply are broadcast through LDS
 // (all lanes of a half read the same 16 bytes); one v_permlane32_swap per value joins the two
-// halves.  Global operands of a step are loaded several steps ahead into a register ring.
+// halves.
+//
+// The loader wave is the only one that reads global memory inside the time loop: it fetches the
+// operands of a step several steps ahead into a register ring and hands them over through LDS.
+// Compute waves only store.  A wave that has both loads and stores in flight cannot wait for "the
+// loads issued N steps ago" (the two complete out of order, so the wait becomes vmcnt(0) and every
+// step would pay a store round trip); with the roles split, neither kind of wave ever waits for a
+// store.
+//
 // Backward also accumulates the weight gradients: dW += dg (x) input is a rank-1 update per step,
 // issued as three v_mfma_f32_32x32x1 (two independent 32x32 blocks: block 0 = dW_ih from the lower
 // half's operands, block 1 = dW_hh from the upper half's), accumulating in AGPRs off the critical
@@ -42,8 +51,7 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 
 // Branch-free predication: every global access in the time loops is a raw buffer access; a lane
 // (or a step) that must not touch memory uses an offset past the end of the buffer, for which loads
-// return 0 and stores are dropped.  An absent tensor gets a descriptor with zero records.  Without
-// control flow around them the loads of a later step stay in flight across the steps in between.
+// return 0 and stores are dropped.  An absent tensor gets a descriptor with zero records.
 constexpr int kOOB = 0x7ffffff0;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
@@ -54,16 +62,28 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int off) {
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
 }
-// row of (t, b) in a caller tensor, -1 if there is none; t must be a valid step of sequence b
-__device__ __forceinline__ int ext_row(const RowMap &m, int t, int b) {
-    if (m.mode == 0) return t * m.B + b;
-    if (m.mode == 1) return b * m.T + t;
-    const int o = m.toff[t];
-    return (b < m.toff[t + 1] - o) ? o + b : -1;
+
+// row of (t, b) in a caller tensor: t*st + b*sb for the padded layouts, a lookup for packed rows
+// (-1 when sequence b has no row at step t); t must be in [0, T)
+struct ExtMap { int st, sb; const int *toff; };
+__device__ __forceinline__ ExtMap ext_map_of(const RowMap &m) {
+    ExtMap e;
+    e.st = m.mode == 1 ? 1 : m.B;
+    e.sb = m.mode == 1 ? m.T : 1;
+    e.toff = m.mode == 2 ? m.toff : nullptr;
+    return e;
+}
+__device__ __forceinline__ int ext_row(const ExtMap &m, int t, int b) {
+    if (m.toff) {
+        const int o = m.toff[t];
+        return (b < m.toff[t + 1] - o) ? o + b : -1;
+    }
+    return t * m.st + b * m.sb;
 }
 
 constexpr int kFwdRing = 8;   // time steps the layer-0 input is loaded ahead
 constexpr int kBwdRing = 4;   // time steps the backward operands are loaded ahead
+constexpr int kOpsLd = 8;     // floats per unit in the backward operand hand-over buffer
 
 }  // namespace vec
 
@@ -71,15 +91,51 @@ constexpr int kBwdRing = 4;   // time steps the backward operands are loaded ahe
 // forward
 // ----------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(512) void gru_vec_fwd_kernel(SmallFwdArgs a) {
+__global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     using namespace vec;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // hb[2][L][KP] | xb[2][KP]
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
-    const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // L = the loader wave
     const int p = lane >> 5, j = lane & 31;
-    const int In_l = (l == 0) ? a.In : H;
     float *xb = smem + 2 * L * KP;
+    const int nticks = T + L - 1;
+
+    if (l == L) {
+        // ---- loader: x[t] of layer 0, kFwdRing steps ahead, into xb[t & 1] -------------------------
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
+        const ExtMap xm = ext_map_of(a.xmap);
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            const int len = a.lengths ? a.lengths[b] : T;
+            auto load_x = [&](int t) -> float {
+                int er = -1;
+                if (t < len) er = ext_row(xm, t, b);
+                return buf_ld(rs_x, (er >= 0 && lane < a.In) ? (er * a.In + lane) * 4 : kOOB);
+            };
+            // xq[u]: the next x[t] with t = u (mod kFwdRing) still to be handed over; x[0] goes to LDS
+            // directly, so slot 0 starts with x[kFwdRing]
+            float xq[kFwdRing];
+#pragma unroll
+            for (int u = 0; u < kFwdRing; ++u) xq[u] = load_x(u == 0 ? kFwdRing : u);
+            const float x0 = load_x(0);
+            if (lane < KP) xb[lane] = x0;
+            lds_barrier();
+            for (int k0 = 0; k0 < nticks; k0 += kFwdRing) {
+#pragma unroll
+                for (int u = 0; u < kFwdRing; ++u) {
+                    const int k = k0 + u;
+                    if (k >= nticks) break;
+                    const int un = (u + 1) % kFwdRing;
+                    if (lane < KP) xb[((k & 1) ^ 1) * KP + lane] = xq[un];
+                    xq[un] = load_x(k + 1 + kFwdRing);
+                    lds_barrier();
+                }
+            }
+        }
+        return;
+    }
+
+    const int In_l = (l == 0) ? a.In : H;
     const long plane = (long)T * B * H;
     const bool unit = j < H;
 
@@ -115,90 +171,67 @@ __global__ __launch_bounds__(512) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     const float b_in = unit ? bi[2 * H + j] : 0.f;
     const float b_hn = unit ? bh[2 * H + j] : 0.f;
     const bool top = l == L - 1;
-    const int nticks = T + L - 1;
     const int tbh = (int)(plane * 4);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(l == 0 ? a.x : nullptr, (long)T * B * a.In * 4);
     const __amdgpu_buffer_rsrc_t rs_yint = make_rsrc(a.y_int[l], tbh);
     const __amdgpu_buffer_rsrc_t rs_yext = make_rsrc(top ? a.y_ext : nullptr, tbh);
     const __amdgpu_buffer_rsrc_t rs_gates = make_rsrc(a.gates[l], 4L * tbh);
     const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(a.h_n, (long)L * B * H * 4);
+    const ExtMap ym = ext_map_of(a.ymap);
+    // LDS addresses: this layer's state (written), and the vector this half multiplies
+    float *hw = smem + l * KP;                                         // + parity * L * KP
+    const float *vsrc = p ? smem + l * KP : (l == 0 ? xb : smem + (l - 1) * KP);
+    const int vpar = (p == 0 && l == 0) ? KP : L * KP;                 // parity stride of vsrc
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int len = a.lengths ? a.lengths[b] : T;
         float hreg = (unit && a.h0) ? a.h0[((long)l * B + b) * H + j] : 0.f;
-
-        // layer-0 input ring: xq[u] holds x[t][j] for the next t = u (mod kFwdRing) still to be handed
-        // to LDS; x[0] goes there directly, so slot 0 starts with x[kFwdRing]
-        float xq[kFwdRing];
-        auto load_x = [&](int t) -> float {
-            int er = -1;
-            if (l == 0 && t < len) er = ext_row(a.xmap, t, b);
-            return buf_ld(rs_x, (er >= 0 && p == 0 && j < a.In) ? (er * a.In + j) * 4 : kOOB);
-        };
-#pragma unroll
-        for (int u = 0; u < kFwdRing; ++u) xq[u] = load_x(u == 0 ? kFwdRing : u);
-        const float x0 = load_x(0);
-
         if (p == 0 && j < KP) {
-            smem[(0 * L + l) * KP + j] = hreg;
-            smem[(1 * L + l) * KP + j] = hreg;
-            if (l == 0) xb[j] = x0;
+            hw[j] = hreg;
+            hw[L * KP + j] = hreg;
         }
         lds_barrier();
 
-        for (int k0 = 0; k0 < nticks; k0 += kFwdRing) {
+        for (int k = 0; k < nticks; ++k) {
+            const int par = k & 1;
+            const int t = k - l;
+            if (t >= 0 && t < T) {
+                const bool active = t < len;
+                const float *src = vsrc + par * vpar;
+                f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
-            for (int u = 0; u < kFwdRing; ++u) {
-                const int k = k0 + u;
-                if (k >= nticks) break;
-                const int par = k & 1;
-                const int t = k - l;
-                if (t >= 0 && t < T) {
-                    const bool active = t < len;
-                    const float *src = p ? smem + (par * L + l) * KP
-                                         : (l == 0 ? xb + par * KP : smem + (par * L + l - 1) * KP);
-                    f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-                    for (int q = 0; q < KP / 4; ++q) {
-                        const float4 v4 = *reinterpret_cast<const float4 *>(src + 4 * q);
-                        const f32x2 va = {v4.x, v4.y}, vb = {v4.z, v4.w};
-                        acc0 = pk_fma(w[0][2 * q], va, acc0); acc1 = pk_fma(w[1][2 * q], va, acc1);
-                        acc2 = pk_fma(w[2][2 * q], va, acc2);
-                        acc0 = pk_fma(w[0][2 * q + 1], vb, acc0); acc1 = pk_fma(w[1][2 * q + 1], vb, acc1);
-                        acc2 = pk_fma(w[2][2 * q + 1], vb, acc2);
-                    }
-                    float gi_r, gh_r, gi_z, gh_z, gi_n, gh_n;
-                    both_halves(acc0.x + acc0.y, gi_r, gh_r);
-                    both_halves(acc1.x + acc1.y, gi_z, gh_z);
-                    both_halves(acc2.x + acc2.y, gi_n, gh_n);
-                    const float r = fast_sigmoid(gi_r + gh_r + b_r);
-                    const float z = fast_sigmoid(gi_z + gh_z + b_z);
-                    const float ghn = gh_n + b_hn;
-                    const float n = fast_tanh(gi_n + b_in + r * ghn);
-                    const float hnew = n + z * (hreg - n);
-                    if (active && unit) hreg = hnew;
-                    const float yv = active ? hreg : 0.f;
-                    if (p == 0 && j < KP) smem[((par ^ 1) * L + l) * KP + j] = hreg;
-                    {
-                        // the two halves hold the same values: each stores half of them
-                        const int oi = ((t * B + b) * H + j) * 4;
-                        const int og = (unit && active) ? oi + (p ? 2 * tbh : 0) : kOOB;
-                        buf_st(rs_gates, og, p ? n : r);                 // planes 0 (r) and 2 (n)
-                        buf_st(rs_gates, og == kOOB ? kOOB : og + tbh, p ? ghn : z);   // planes 1 (z) and 3 (gh_n)
-                        buf_st(rs_yint, (unit && p == 0) ? oi : kOOB, yv);
-                        int er = -1;
-                        if (top && (active || a.ymap.mode != 2)) er = ext_row(a.ymap, t, b);
-                        buf_st(rs_yext, (unit && p == 1 && er >= 0) ? (er * H + j) * 4 : kOOB, yv);
-                        if (t == len - 1) buf_st(rs_hn, (unit && p == 0) ? ((l * B + b) * H + j) * 4 : kOOB, yv);
-                    }
+                for (int q = 0; q < KP / 4; ++q) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(src + 4 * q);
+                    const f32x2 va = {v4.x, v4.y}, vb = {v4.z, v4.w};
+                    acc0 = pk_fma(w[0][2 * q], va, acc0); acc1 = pk_fma(w[1][2 * q], va, acc1);
+                    acc2 = pk_fma(w[2][2 * q], va, acc2);
+                    acc0 = pk_fma(w[0][2 * q + 1], vb, acc0); acc1 = pk_fma(w[1][2 * q + 1], vb, acc1);
+                    acc2 = pk_fma(w[2][2 * q + 1], vb, acc2);
                 }
-                if (l == 0) {   // hand x[k+1] to the next tick, refill the ring slot
-                    const int un = (u + 1) % kFwdRing;
-                    if (p == 0 && j < KP) xb[(par ^ 1) * KP + j] = xq[un];
-                    xq[un] = load_x(k + 1 + kFwdRing);
+                float gi_r, gh_r, gi_z, gh_z, gi_n, gh_n;
+                both_halves(acc0.x + acc0.y, gi_r, gh_r);
+                both_halves(acc1.x + acc1.y, gi_z, gh_z);
+                both_halves(acc2.x + acc2.y, gi_n, gh_n);
+                const float r = fast_sigmoid(gi_r + gh_r + b_r);
+                const float z = fast_sigmoid(gi_z + gh_z + b_z);
+                const float ghn = gh_n + b_hn;
+                const float n = fast_tanh(gi_n + b_in + r * ghn);
+                const float hnew = n + z * (hreg - n);
+                if (active && unit) hreg = hnew;
+                const float yv = active ? hreg : 0.f;
+                if (p == 0 && j < KP) hw[(par ^ 1) * L * KP + j] = hreg;
+                // the two halves hold the same values: each stores half of them
+                const int oi = ((t * B + b) * H + j) * 4;
+                const int og = (unit && active) ? oi + (p ? 2 * tbh : 0) : kOOB;
+                buf_st(rs_gates, og, p ? n : r);                               // planes 0 (r) and 2 (n)
+                buf_st(rs_gates, og == kOOB ? kOOB : og + tbh, p ? ghn : z);   // planes 1 (z) and 3 (gh_n)
+                buf_st(rs_yint, (unit && p == 0) ? oi : kOOB, yv);
+                if (top) {
+                    const int er = ext_row(ym, t, b);
+                    buf_st(rs_yext, (unit && p == 1 && er >= 0) ? (er * H + j) * 4 : kOOB, yv);
                 }
-                lds_barrier();
+                if (t == len - 1) buf_st(rs_hn, (unit && p == 0) ? ((l * B + b) * H + j) * 4 : kOOB, yv);
             }
+            lds_barrier();
         }
     }
 }
@@ -207,17 +240,102 @@ __global__ __launch_bounds__(512) void gru_vec_fwd_kernel(SmallFwdArgs a) {
 // backward (dx, dh0 and per-workgroup partial weight / bias gradients)
 // ----------------------------------------------------------------------------------------------
 template <int KP>
-__global__ __launch_bounds__(256) void gru_vec_bwd_kernel(SmallBwdArgs a) {
+__global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     using namespace vec;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // gv[L][4][KP] | dxb[2][L][KP]
+    // gv[L][4][KP] | dxb[2][L][KP] | ops[2][L][32][kOpsLd]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
-    const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // L = the loader wave
     const int p = lane >> 5, j = lane & 31;
+    float *dxb = smem + L * 4 * KP;
+    float *ops = dxb + 2 * L * KP;
+    const long plane = (long)T * B * H;
+    const int tbh = (int)(plane * 4);
+    const int nticks = T + L - 1;
+
+    if (l == L) {
+        // ---- loader: per layer and step  r z n gh_n | h_{t-1} | dy | layer input, kBwdRing ahead ----
+        // lower half: r, n, h_{t-1}, dy, input;  upper half: z, gh_n
+        const ExtMap dym = ext_map_of(a.dymap), xm = ext_map_of(a.xmap);
+        const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(a.dy_ext, tbh);
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
+        struct LOps { float g0, g1, hp, xin; };
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            const int len = a.lengths ? a.lengths[b] : T;
+            LOps ring[kBwdRing][kSmallMaxL / 2];
+            float dyr[kBwdRing];
+            auto load_tick = [&](int k, LOps (&dst)[kSmallMaxL / 2], float &dy) {
+                dy = 0.f;
+#pragma unroll
+                for (int q = 0; q < kSmallMaxL / 2; ++q) {
+                    if (q >= L) break;
+                    const int t = T - 1 - k + (L - 1 - q);
+                    const bool ok = t >= 0 && t < len;
+                    const int In_q = q == 0 ? a.In : H;
+                    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gates[q], 4L * tbh);
+                    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y_int[q], tbh);
+                    const int oi = ((t * B + b) * H + j) * 4;
+                    const int og = (ok && j < H) ? oi + (p ? tbh : 0) : kOOB;
+                    dst[q].g0 = buf_ld(rs_g, og);                                  // r | z
+                    dst[q].g1 = buf_ld(rs_g, og == kOOB ? kOOB : og + 2 * tbh);    // n | gh_n
+                    dst[q].hp = buf_ld(rs_y, (ok && t > 0 && j < H && p == 0) ? oi - B * H * 4 : kOOB);
+                    if (q == 0) {
+                        int er = -1;
+                        if (ok) er = ext_row(xm, t, b);
+                        dst[q].xin = buf_ld(rs_x, (er >= 0 && j < In_q && p == 0) ? (er * In_q + j) * 4 : kOOB);
+                    } else {
+                        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.y_int[q - 1], tbh);
+                        dst[q].xin = buf_ld(rs_in, (ok && j < H && p == 0) ? oi : kOOB);
+                    }
+                    if (q == L - 1) {
+                        int er = -1;
+                        if (ok) er = ext_row(dym, t, b);
+                        dy = buf_ld(rs_dy, (er >= 0 && j < H && p == 0) ? (er * H + j) * 4 : kOOB);
+                    }
+                }
+            };
+            auto hand_over = [&](int k, const LOps (&src)[kSmallMaxL / 2], float dy) {
+                float *dst = ops + (k & 1) * L * 32 * kOpsLd + j * kOpsLd;
+#pragma unroll
+                for (int q = 0; q < kSmallMaxL / 2; ++q) {
+                    if (q >= L) break;
+                    float *d = dst + q * 32 * kOpsLd;
+                    d[p] = src[q].g0;           // [0] r  [1] z
+                    d[2 + p] = src[q].g1;       // [2] n  [3] gh_n
+                    if (p == 0) {
+                        d[4] = src[q].hp;
+                        d[5] = (q == L - 1) ? dy : 0.f;
+                        d[6] = src[q].xin;
+                    }
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < kBwdRing; ++u) load_tick(u == 0 ? kBwdRing : u, ring[u], dyr[u]);
+            {
+                LOps first[kSmallMaxL / 2];
+                float dy0;
+                load_tick(0, first, dy0);
+                hand_over(0, first, dy0);
+            }
+            lds_barrier();
+            for (int k0 = 0; k0 < nticks; k0 += kBwdRing) {
+#pragma unroll
+                for (int u = 0; u < kBwdRing; ++u) {
+                    const int k = k0 + u;
+                    if (k >= nticks) break;
+                    const int un = (u + 1) % kBwdRing;
+                    hand_over(k + 1, ring[un], dyr[un]);
+                    load_tick(k + 1 + kBwdRing, ring[un], dyr[un]);
+                    lds_barrier();
+                }
+            }
+        }
+        return;
+    }
+
     const int In_l = (l == 0) ? a.In : H;
     float *gv = smem + l * 4 * KP;
-    float *dxb = smem + L * 4 * KP;
-    const long plane = (long)T * B * H;
     const bool unit = j < H;
     const bool top = l == L - 1;
     const int ncol = p ? H : In_l;           // columns this half owns
@@ -244,112 +362,78 @@ __global__ __launch_bounds__(256) void gru_vec_bwd_kernel(SmallBwdArgs a) {
         for (int r = 0; r < 32; ++r) dWa[g][r] = 0.f;
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const int nticks = T + L - 1;
-    const int tbh = (int)(plane * 4);
-    const __amdgpu_buffer_rsrc_t rs_gates = make_rsrc(a.gates[l], 4L * tbh);
-    const __amdgpu_buffer_rsrc_t rs_yint = make_rsrc(a.y_int[l], tbh);
-    const __amdgpu_buffer_rsrc_t rs_h0 = make_rsrc(a.h0, (long)L * B * H * 4);
-    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(top ? a.dy_ext : nullptr, tbh);
-    const __amdgpu_buffer_rsrc_t rs_dhn = make_rsrc(a.dh_n, (long)L * B * H * 4);
-    const __amdgpu_buffer_rsrc_t rs_xin = l == 0 ? make_rsrc(a.x, (long)T * B * a.In * 4) : make_rsrc(a.y_int[l - 1], tbh);
     const __amdgpu_buffer_rsrc_t rs_dx = make_rsrc(l == 0 ? a.dx_ext : nullptr, (long)T * B * a.In * 4);
-
-    struct Ops { float r, z, n, hn, hp, dy, xin; };
+    const ExtMap dxm = ext_map_of(a.dxmap);
+    const float *myops = ops + (l * 32 + j) * kOpsLd;
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int len = a.lengths ? a.lengths[b] : T;
         // the gradient of h_n enters as the initial carry: steps past the length pass it through
-        const int sb = ((l * B + b) * H + j) * 4;
-        float dhc = buf_ld(rs_dhn, unit ? sb : kOOB);
-        const float h0v = buf_ld(rs_h0, unit ? sb : kOOB);
+        const long sb = ((long)l * B + b) * H + j;
+        float dhc = (a.dh_n && unit) ? a.dh_n[sb] : 0.f;
+        const float h0v = (a.h0 && unit) ? a.h0[sb] : 0.f;
+        lds_barrier();
 
-        auto load_ops = [&](int t) -> Ops {
-            const bool ok = t >= 0 && t < len;
-            const int oi = ((t * B + b) * H + j) * 4;
-            const int ou = (ok && unit) ? oi : kOOB;
-            Ops o;
-            o.r = buf_ld(rs_gates, ou);
-            o.z = buf_ld(rs_gates, ou == kOOB ? kOOB : ou + tbh);
-            o.n = buf_ld(rs_gates, ou == kOOB ? kOOB : ou + 2 * tbh);
-            o.hn = buf_ld(rs_gates, ou == kOOB ? kOOB : ou + 3 * tbh);
-            // h_{t-1}: both halves (p = 1 multiplies it into dW_hh)
-            o.hp = buf_ld(rs_yint, (ok && unit && t > 0) ? oi - B * H * 4 : kOOB);
-            int er = -1;
-            if (ok && top) er = ext_row(a.dymap, t, b);
-            o.dy = buf_ld(rs_dy, (er >= 0 && unit) ? (er * H + j) * 4 : kOOB);
-            int xr = ok ? t * B + b : -1;
-            if (ok && l == 0) xr = ext_row(a.xmap, t, b);
-            o.xin = buf_ld(rs_xin, (xr >= 0 && col && p == 0) ? (xr * In_l + j) * 4 : kOOB);
-            return o;
-        };
-        auto tick_time = [&](int k) { return T - 1 - k + (L - 1 - l); };
-
-        Ops ring[kBwdRing];
-#pragma unroll
-        for (int u = 0; u < kBwdRing; ++u) ring[u] = load_ops(tick_time(u));
-
-        for (int k0 = 0; k0 < nticks; k0 += kBwdRing) {
-#pragma unroll
-            for (int u = 0; u < kBwdRing; ++u) {
-                const int k = k0 + u;
-                if (k >= nticks) break;
-                const int par = k & 1;
-                const int t = tick_time(k);
-                if (t >= 0 && t < T) {
-                    const bool active = t < len;
-                    Ops o = ring[u];
-                    if (t == 0) o.hp = h0v;
-                    float dyv = o.dy;
-                    if (!top && j < KP) dyv += dxb[((par ^ 1) * L + (l + 1)) * KP + j];
-                    const bool on = active && unit;      // both halves run the gate arithmetic
-                    const float d = on ? dyv + dhc : 0.f;
-                    const float dn = d * (1.f - o.z);
-                    const float dzz = d * (o.hp - o.n);
-                    const float an = dn * (1.f - o.n * o.n);
-                    const float dar = an * o.hn * o.r * (1.f - o.r);
-                    const float daz = dzz * o.z * (1.f - o.z);
-                    const float dgn = an * o.r;
-                    const float keep = on ? d * o.z : dhc;
-                    if (j < KP) {   // each half publishes two of the four vectors
-                        gv[(p ? 1 : 0) * KP + j] = p ? daz : dar;
-                        gv[(p ? 3 : 2) * KP + j] = p ? dgn : an;
-                    }
-                    dbs[0] += dar; dbs[1] += daz; dbs[2] += an; dbs[3] += dgn;
-                    // rank-1 weight-gradient updates: rows from this half's dg, columns from its input
-                    const float s = p ? o.hp : o.xin;
-                    dWa[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(dar, s, dWa[0], 0, 0, 0);
-                    dWa[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(daz, s, dWa[1], 0, 0, 0);
-                    dWa[2] = __builtin_amdgcn_mfma_f32_32x32x1f32(p ? dgn : an, s, dWa[2], 0, 0, 0);
-                    // same wave wrote the vectors: LDS executes a wave's accesses in order
-                    f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-                    for (int q = 0; q < KP / 4; ++q) {
-                        const float4 u0 = *reinterpret_cast<const float4 *>(gv + 0 * KP + 4 * q);
-                        const float4 u1 = *reinterpret_cast<const float4 *>(gv + 1 * KP + 4 * q);
-                        const float4 u2 = *reinterpret_cast<const float4 *>(gv + (p ? 3 : 2) * KP + 4 * q);
-                        const f32x2 a0 = {u0.x, u0.y}, b0 = {u0.z, u0.w};
-                        const f32x2 a1 = {u1.x, u1.y}, b1 = {u1.z, u1.w};
-                        const f32x2 a2 = {u2.x, u2.y}, b2 = {u2.z, u2.w};
-                        acc0 = pk_fma(wT[0][2 * q], a0, acc0); acc0 = pk_fma(wT[0][2 * q + 1], b0, acc0);
-                        acc1 = pk_fma(wT[1][2 * q], a1, acc1); acc1 = pk_fma(wT[1][2 * q + 1], b1, acc1);
-                        acc2 = pk_fma(wT[2][2 * q], a2, acc2); acc2 = pk_fma(wT[2][2 * q + 1], b2, acc2);
-                    }
-                    const f32x2 sum = acc0 + acc1 + acc2;
-                    float dxv, dhv;
-                    both_halves(sum.x + sum.y, dxv, dhv);
-                    dhc = keep + (on ? dhv : 0.f);
-                    if (l > 0 && p == 0 && j < KP) dxb[(par * L + l) * KP + j] = dxv;
-                    if (l == 0) {
-                        int er = -1;
-                        if (active || a.dxmap.mode != 2) er = ext_row(a.dxmap, t, b);
-                        buf_st(rs_dx, (er >= 0 && p == 0 && j < a.In) ? (er * a.In + j) * 4 : kOOB, dxv);
-                    }
+        for (int k = 0; k < nticks; ++k) {
+            const int par = k & 1;
+            const int t = T - 1 - k + (L - 1 - l);
+            if (t >= 0 && t < T) {
+                const bool active = t < len;
+                const float4 oa = *reinterpret_cast<const float4 *>(myops + par * L * 32 * kOpsLd);
+                const float4 ob = *reinterpret_cast<const float4 *>(myops + par * L * 32 * kOpsLd + 4);
+                const float o_r = oa.x, o_z = oa.y, o_n = oa.z, o_hn = oa.w;
+                const float o_hp = (t == 0) ? h0v : ob.x;
+                const float o_xin = ob.z;
+                float dyv = ob.y;
+                if (!top && j < KP) dyv += dxb[((par ^ 1) * L + (l + 1)) * KP + j];
+                const bool on = active && unit;      // both halves run the gate arithmetic
+                const float d = on ? dyv + dhc : 0.f;
+                const float dn = d * (1.f - o_z);
+                const float dzz = d * (o_hp - o_n);
+                const float an = dn * (1.f - o_n * o_n);
+                const float dar = an * o_hn * o_r * (1.f - o_r);
+                const float daz = dzz * o_z * (1.f - o_z);
+                const float dgn = an * o_r;
+                const float keep = on ? d * o_z : dhc;
+                if (j < KP) {   // each half publishes two of the four vectors
+                    gv[(p ? 1 : 0) * KP + j] = p ? daz : dar;
+                    gv[(p ? 3 : 2) * KP + j] = p ? dgn : an;
                 }
-                ring[u] = load_ops(tick_time(k + kBwdRing));
-                lds_barrier();
+                dbs[0] += dar; dbs[1] += daz; dbs[2] += an; dbs[3] += dgn;
+                // rank-1 weight-gradient updates: rows from this half's dg, columns from its input
+                const float s = p ? o_hp : o_xin;
+                dWa[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(dar, s, dWa[0], 0, 0, 0);
+                dWa[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(daz, s, dWa[1], 0, 0, 0);
+                dWa[2] = __builtin_amdgcn_mfma_f32_32x32x1f32(p ? dgn : an, s, dWa[2], 0, 0, 0);
+                // same wave wrote the vectors: LDS executes a wave's accesses in order
+                f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#pragma unroll
+                for (int q = 0; q < KP / 4; ++q) {
+                    const float4 u0 = *reinterpret_cast<const float4 *>(gv + 0 * KP + 4 * q);
+                    const float4 u1 = *reinterpret_cast<const float4 *>(gv + 1 * KP + 4 * q);
+                    const float4 u2 = *reinterpret_cast<const float4 *>(gv + (p ? 3 : 2) * KP + 4 * q);
+                    acc0 = pk_fma(wT[0][2 * q], (f32x2){u0.x, u0.y}, acc0);
+                    acc0 = pk_fma(wT[0][2 * q + 1], (f32x2){u0.z, u0.w}, acc0);
+                    acc1 = pk_fma(wT[1][2 * q], (f32x2){u1.x, u1.y}, acc1);
+                    acc1 = pk_fma(wT[1][2 * q + 1], (f32x2){u1.z, u1.w}, acc1);
+                    acc2 = pk_fma(wT[2][2 * q], (f32x2){u2.x, u2.y}, acc2);
+                    acc2 = pk_fma(wT[2][2 * q + 1], (f32x2){u2.z, u2.w}, acc2);
+                }
+                const f32x2 sum = acc0 + acc1 + acc2;
+                float dxv, dhv;
+                both_halves(sum.x + sum.y, dxv, dhv);
+                dhc = keep + (on ? dhv : 0.f);
+                if (l > 0) {
+                    if (p == 0 && j < KP) dxb[(par * L + l) * KP + j] = dxv;
+                } else {
+                    int er = -1;
+                    if (active || !dxm.toff) er = ext_row(dxm, t, b);
+                    buf_st(rs_dx, (er >= 0 && p == 0 && j < a.In) ? (er * a.In + j) * 4 : kOOB, dxv);
+                }
             }
+            lds_barrier();
         }
-        if (a.dh0 && p == 0 && unit) a.dh0[((long)l * B + b) * H + j] = dhc;
+        if (a.dh0 && p == 0 && unit) a.dh0[sb] = dhc;
     }
 
     // ---- per-workgroup partial gradients: slab laid out like the gradients themselves -------------
@@ -378,11 +462,14 @@ __global__ __launch_bounds__(256) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     }
 }
 
-int gru_vec_workgroups(int B) { return B < 512 ? B : 512; }
+// Workgroups of the two kernels (each loops over its share of the sequences).  The backward kernel
+// fits one workgroup per CU; its count is also the number of partial weight gradients.
+int gru_vec_workgroups(int B) { return B < 256 ? B : 256; }
+static int fwd_workgroups(int B) { return B < 512 ? B : 512; }
 
 // Up to 2048 sequences and 4 layers; byte offsets into every per-(t,b) buffer must fit 31 bits.
 bool gru_vec_supported(int B, int T, int In, int H, int L) {
-    if (H > 32 || In > 32 || L > 4 || B > 2048) return false;   // 4 waves: the backward kernel needs > 256 registers
+    if (H > 32 || In > 32 || L > 4 || B > 2048) return false;
     const long widest = H > In ? H : In;
     return (long)T * B * widest * 16 < (1L << 31);
 }
@@ -390,7 +477,7 @@ bool gru_vec_supported(int B, int T, int In, int H, int L) {
 hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
-    dim3 grid(gru_vec_workgroups(a.B)), block(64 * a.L);
+    dim3 grid(fwd_workgroups(a.B)), block(64 * (a.L + 1));
     const size_t lds = (size_t)(2 * a.L + 2) * KP * sizeof(float);
     if (k24) hipLaunchKernelGGL(gru_vec_fwd_kernel<24>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(gru_vec_fwd_kernel<32>, grid, block, lds, s, a);
@@ -400,8 +487,8 @@ hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s) {
 hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
-    dim3 grid(gru_vec_workgroups(a.B)), block(64 * a.L);
-    const size_t lds = (size_t)(4 * a.L + 2 * a.L) * KP * sizeof(float);
+    dim3 grid(gru_vec_workgroups(a.B)), block(64 * (a.L + 1));
+    const size_t lds = (size_t)((4 * a.L + 2 * a.L) * KP + 2 * a.L * 32 * vec::kOpsLd) * sizeof(float);
     if (k24) hipLaunchKernelGGL(gru_vec_bwd_kernel<24>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(gru_vec_bwd_kernel<32>, grid, block, lds, s, a);
     return hipGetLastError();

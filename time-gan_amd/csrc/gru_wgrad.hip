@@ -5,8 +5,8 @@
 // Stage 1 (grid = row chunks x layers): a workgroup streams its rows of dg / xin / h_prev through
 // LDS with fully coalesced loads (every byte is fetched once per workgroup) and multiplies all
 // output tiles of its layer on the MFMA; partial tiles go to a slab per chunk.
-// Stage 2: one thread per gradient element sums the slabs in chunk order (deterministic), adds the
-// bias gradients from the backward kernel's per-workgroup partial sums.
+// Stage 2: sums the slabs (and the backward kernel's per-workgroup bias partials) per gradient
+// element in a fixed order.
 #include "tgru_internal.h"
 
 namespace tgru {
@@ -124,24 +124,44 @@ __global__ __launch_bounds__(512) void gru_wgrad_partial_kernel(SmallWgradArgs a
     }
 }
 
+constexpr int kRedElems = 32;    // gradient elements per workgroup of the reduce kernel
+constexpr int kRedGroups = 8;    // slab groups summed in parallel per element
+
+// Stage 2: workgroup = 32 gradient elements x 8 groups of slabs.  Each thread sums its group's
+// contiguous range of partials (four interleaved sums, independent loads in flight together), the
+// eight group sums are combined in a fixed order: the result does not depend on timing.
 __global__ __launch_bounds__(256) void gru_wgrad_reduce_kernel(SmallWgradArgs a) {
+    __shared__ float part[kRedGroups][kRedElems];
     const int H = a.H, L = a.L;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < a.slab_stride) {
-        // fixed summation order (four interleaved partial sums, then a fixed combine); the loads of
-        // one thread are independent, so they are all in flight together
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        const float *sp = a.slabs + idx;
-        int c = 0;
-#pragma unroll 4
-        for (; c + 3 < a.nchunks; c += 4) {
-            v0 += sp[(long)c * a.slab_stride];
-            v1 += sp[(long)(c + 1) * a.slab_stride];
-            v2 += sp[(long)(c + 2) * a.slab_stride];
-            v3 += sp[(long)(c + 3) * a.slab_stride];
+    const int e = threadIdx.x & (kRedElems - 1), grp = threadIdx.x / kRedElems;
+    const long idx = (long)blockIdx.x * kRedElems + e;
+    const long nb = (long)L * 4 * H;
+    const bool is_w = idx < a.slab_stride;
+    const bool valid = idx < a.slab_stride + nb;
+    // partial k of this element is at base[k * stride], k < count
+    const float *base = is_w ? a.slabs + idx : a.db_part + (idx - a.slab_stride);
+    const long stride = is_w ? a.slab_stride : nb;
+    const int count = is_w ? a.nchunks : a.nblk;
+    const int per = (count + kRedGroups - 1) / kRedGroups;
+    const int c0 = grp * per, c1 = min(count, c0 + per);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (valid) {
+        int c = c0;
+        for (; c + 3 < c1; c += 4) {
+            v0 += base[(long)c * stride];
+            v1 += base[(long)(c + 1) * stride];
+            v2 += base[(long)(c + 2) * stride];
+            v3 += base[(long)(c + 3) * stride];
         }
-        for (; c < a.nchunks; ++c) v0 += sp[(long)c * a.slab_stride];
-        const float v = (v0 + v1) + (v2 + v3);
+        for (; c < c1; ++c) v0 += base[(long)c * stride];
+    }
+    part[grp][e] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (grp != 0 || !valid) return;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < kRedGroups; ++g) v += part[g][e];
+    if (is_w) {
         long rem = idx;
         for (int l = 0; l < L; ++l) {
             const long n_ih = 3L * H * (l == 0 ? a.In : H), n_hh = 3L * H * H;
@@ -152,11 +172,8 @@ __global__ __launch_bounds__(256) void gru_wgrad_reduce_kernel(SmallWgradArgs a)
         }
         return;
     }
-    idx -= a.slab_stride;
-    if (idx >= (long)L * 4 * H) return;
-    const int l = (int)(idx / (4 * H)), i = (int)(idx % (4 * H));
-    float v = 0.f;
-    for (int k = 0; k < a.nblk; ++k) v += a.db_part[((long)k * L + l) * 4 * H + i];
+    const long bi = idx - a.slab_stride;
+    const int l = (int)(bi / (4 * H)), i = (int)(bi % (4 * H));
     if (i < 3 * H) {
         a.db_ih[l][i] = a.accumulate ? a.db_ih[l][i] + v : v;
         if (i < 2 * H) a.db_hh[l][i] = a.accumulate ? a.db_hh[l][i] + v : v;
@@ -186,7 +203,8 @@ hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
 
 hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, hipStream_t s) {
     const long items = a.slab_stride + (long)a.L * 4 * a.H;
-    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)((items + kRedElems - 1) / kRedElems)),
+                       dim3(kRedElems * kRedGroups), 0, s, a);
     return hipGetLastError();
 }
 
