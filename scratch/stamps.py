@@ -4,7 +4,7 @@ import timegan_amd as tg
 from timegan_amd import _lib
 _lib.LIB_PATH = _lib.LIB_PATH.replace('libtgru.so', 'libtgru_stamps.so')
 dev = torch.device('cuda:0')
-B,T,In,H,L = 128,24,24,24,3
+B,T,In,H,L = 128,96,24,24,3
 w=[]
 for l in range(L):
     for s in ((3*H, In if l==0 else H),(3*H,H),(3*H,),(3*H,)): w.append((torch.rand(s, device=dev)*2-1)/H**0.5)
@@ -13,6 +13,6 @@ r = tg.GRURunner(B,T,In,H,L,tg.LAYOUT_TBF,dev); r.set_weights(w)
 for _ in range(50): r.forward(x); r.backward(dy)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong*128)()
-_lib.lib().tgru_debug_stamps_h24.argtypes=[ctypes.c_void_p]; print('rc', _lib.lib().tgru_debug_stamps_h24(out))
+_lib.lib().tgru_debug_stamps_vec.argtypes=[ctypes.c_void_p]; print('rc', _lib.lib().tgru_debug_stamps_vec(out))
 a = np.array(out[:]).reshape(16,8)[:6,:6]
-print('per wave cycles: [flush, lds-read/issue, mfma, elementwise, barrier, loop-top]'); print(a); print('per tick:', a.sum(1)/26)
+print('per wave cycles: [0 reads+flush, 1 fma, 2 gates, 3 bookkeeping, 4 barrier, 5 loop-top]'); print(a); print('per tick:', a.sum(1)/98, a/98)

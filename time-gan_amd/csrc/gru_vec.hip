@@ -33,6 +33,29 @@
 #include "tgru_internal.h"
 
 namespace tgru {
+
+#ifdef TGRU_STAMPS   // diagnostic build only: per-wave cycle counts of the forward tick's phases
+__device__ unsigned long long tgru_stamps_vec[16 * 8];
+#define VSTAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define VSTAMP(k)                                                  \
+    do {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += now_ - st_last; st_last = now_;               \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    } while (0)
+#define VSTAMP_FLUSH                                                         \
+    if (blockIdx.x == 0 && lane == 0)                                        \
+        for (int k_ = 0; k_ < 6; ++k_) tgru_stamps_vec[l * 8 + k_] = st_acc[k_];
+extern "C" int tgru_debug_stamps_vec(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgru_stamps_vec), sizeof(unsigned long long) * 16 * 8);
+}
+#else
+#define VSTAMP_DECL
+#define VSTAMP(k)
+#define VSTAMP_FLUSH
+#endif
+
 namespace vec {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -46,6 +69,11 @@ __device__ __forceinline__ void both_halves(float v, float &lo, float &hi) {
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
 }
+
+// Waits for every outstanding global load of this wave.  Placed in front of a time loop so that the
+// compiler does not put its own wait for the loop-invariant operands (weights) INSIDE the loop,
+// where, from the second step on, it would wait for that step's stores instead.
+__device__ __forceinline__ void wait_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -62,28 +90,55 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int off) {
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, int off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_st2(__amdgpu_buffer_rsrc_t r, int off, float a, float b) {
+    const u32x2 u = {__float_as_uint(a), __float_as_uint(b)};
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// Direct-to-LDS loads: lane i's element lands at lds + i * size, no VGPR is involved and the compiler
+// tracks nothing: the issuing wave waits with an explicit vmcnt before the barrier that publishes
+// the data.  Out-of-range lanes write 0.
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void lds_load_b32(__amdgpu_buffer_rsrc_t r, float *lds, int off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 4, off, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_load_b128(__amdgpu_buffer_rsrc_t r, float *lds, int off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, off, 0, 0, 0);
+}
+// s_waitcnt vmcnt(n) alone (expcnt and lgkmcnt fields left at "no wait")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
 
-// row of (t, b) in a caller tensor: t*st + b*sb for the padded layouts, a lookup for packed rows
-// (-1 when sequence b has no row at step t); t must be in [0, T)
-struct ExtMap { int st, sb; const int *toff; };
+// lane offset + step offset; either may be kOOB (both < 2^31, so the unsigned sum stays out of range)
+__device__ __forceinline__ int off_add(int lane_off, int step_off) { return (int)((unsigned)lane_off + (unsigned)step_off); }
+
+// row of (t, b) in a caller tensor of one of the two padded layouts: t*st + b*sb (packed rows are
+// not handled by these kernels: the library routes them to the MFMA whole-stack kernels)
+struct ExtMap { int st, sb; };
 __device__ __forceinline__ ExtMap ext_map_of(const RowMap &m) {
     ExtMap e;
     e.st = m.mode == 1 ? 1 : m.B;
     e.sb = m.mode == 1 ? m.T : 1;
-    e.toff = m.mode == 2 ? m.toff : nullptr;
     return e;
 }
-__device__ __forceinline__ int ext_row(const ExtMap &m, int t, int b) {
-    if (m.toff) {
-        const int o = m.toff[t];
-        return (b < m.toff[t + 1] - o) ? o + b : -1;
-    }
-    return t * m.st + b * m.sb;
-}
+__device__ __forceinline__ int ext_row(const ExtMap &m, int t, int b) { return t * m.st + b * m.sb; }
 
-constexpr int kFwdRing = 8;   // time steps the layer-0 input is loaded ahead
-constexpr int kBwdRing = 4;   // time steps the backward operands are loaded ahead
-constexpr int kOpsLd = 8;     // floats per unit in the backward operand hand-over buffer
+constexpr int kVecMaxL = 4;   // layers (compute waves) per workgroup
+constexpr int kFwdAhead = 8;  // time steps the layer-0 input is loaded ahead
+constexpr int kFwdSlots = kFwdAhead + 1;
+constexpr int kBwdAhead = 4;  // time steps the backward operands are loaded ahead
+constexpr int kBwdSlots = kBwdAhead + 1;
+// one backward operand slot (floats): gates[kVecMaxL][32][4] | y[kVecMaxL][32] | x0[32] | dy[32]
+constexpr int kSlotG = 0, kSlotY = kVecMaxL * 128, kSlotX = kSlotY + kVecMaxL * 32, kSlotD = kSlotX + 32;
+constexpr int kSlotFloats = kSlotD + 32;
+constexpr int kBwdLoads = 2 * kVecMaxL + 2;   // direct-to-LDS loads per step
 
 }  // namespace vec
 
@@ -93,7 +148,7 @@ constexpr int kOpsLd = 8;     // floats per unit in the backward operand hand-ov
 template <int KP>
 __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     using namespace vec;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // hb[2][L][KP] | xb[2][KP]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // hb[2][L][KP] | xb[kFwdSlots][32]
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
     const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // L = the loader wave
@@ -102,35 +157,25 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     const int nticks = T + L - 1;
 
     if (l == L) {
-        // ---- loader: x[t] of layer 0, kFwdRing steps ahead, into xb[t & 1] -------------------------
+        // ---- loader: x[t] of layer 0 straight into LDS slot t % kFwdSlots, kFwdAhead steps ahead ----
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
         const ExtMap xm = ext_map_of(a.xmap);
+        const int xstep = xm.st * a.In * 4;
         for (int b = blockIdx.x; b < B; b += gridDim.x) {
             const int len = a.lengths ? a.lengths[b] : T;
-            auto load_x = [&](int t) -> float {
-                int er = -1;
-                if (t < len) er = ext_row(xm, t, b);
-                return buf_ld(rs_x, (er >= 0 && lane < a.In) ? (er * a.In + lane) * 4 : kOOB);
+            const int xbase = lane < a.In ? (b * xm.sb * a.In + lane) * 4 : kOOB;
+            auto issue = [&](int t) {   // lanes 0..31; lanes >= In and steps >= len write zeros
+                if (lane < 32) lds_load_b32(rs_x, xb + (t % kFwdSlots) * 32, off_add(xbase, t < len ? t * xstep : kOOB));
             };
-            // xq[u]: the next x[t] with t = u (mod kFwdRing) still to be handed over; x[0] goes to LDS
-            // directly, so slot 0 starts with x[kFwdRing]
-            float xq[kFwdRing];
-#pragma unroll
-            for (int u = 0; u < kFwdRing; ++u) xq[u] = load_x(u == 0 ? kFwdRing : u);
-            const float x0 = load_x(0);
-            if (lane < KP) xb[lane] = x0;
+            for (int t = 0; t < kFwdAhead; ++t) issue(t);
+            wait_vmcnt<kFwdAhead - 1>();
             lds_barrier();
-            for (int k0 = 0; k0 < nticks; k0 += kFwdRing) {
-#pragma unroll
-                for (int u = 0; u < kFwdRing; ++u) {
-                    const int k = k0 + u;
-                    if (k >= nticks) break;
-                    const int un = (u + 1) % kFwdRing;
-                    if (lane < KP) xb[((k & 1) ^ 1) * KP + lane] = xq[un];
-                    xq[un] = load_x(k + 1 + kFwdRing);
-                    lds_barrier();
-                }
+            for (int k = 0; k < nticks; ++k) {
+                issue(k + kFwdAhead);
+                wait_vmcnt<kFwdAhead - 1>();     // x[k+1] has landed
+                lds_barrier();
             }
+            wait_vmcnt<0>();                     // the slots are reused by the next sequence
         }
         return;
     }
@@ -179,8 +224,8 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     const ExtMap ym = ext_map_of(a.ymap);
     // LDS addresses: this layer's state (written), and the vector this half multiplies
     float *hw = smem + l * KP;                                         // + parity * L * KP
-    const float *vsrc = p ? smem + l * KP : (l == 0 ? xb : smem + (l - 1) * KP);
-    const int vpar = (p == 0 && l == 0) ? KP : L * KP;                 // parity stride of vsrc
+    const bool from_x = p == 0 && l == 0;
+    const float *vsrc = p ? smem + l * KP : smem + (l - 1) * KP;       // + parity * L * KP
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int len = a.lengths ? a.lengths[b] : T;
@@ -189,25 +234,47 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
             hw[j] = hreg;
             hw[L * KP + j] = hreg;
         }
+        wait_loads();
         lds_barrier();
 
+        // results of a step are stored at the top of the next one, in the shadow of its LDS reads
+        float q_a = 0.f, q_b = 0.f, q_y = 0.f;
+        int q_og = kOOB, q_oi = kOOB, q_oe = kOOB;
+        bool q_last = false;
+        auto flush = [&]() {
+            buf_st2(rs_gates, q_og, q_a, q_b);        // [row][unit][r z | n gh_n]: each half stores a pair
+            buf_st(rs_yint, q_oi, q_y);
+            buf_st(rs_yext, q_oe, q_y);
+            if (q_last) buf_st(rs_hn, (unit && p == 0) ? ((l * B + b) * H + j) * 4 : kOOB, q_y);
+        };
+
+        VSTAMP_DECL
         for (int k = 0; k < nticks; ++k) {
             const int par = k & 1;
             const int t = k - l;
-            if (t >= 0 && t < T) {
+            const bool work = t >= 0 && t < T;
+            VSTAMP(5);
+            if (work) {
                 const bool active = t < len;
-                const float *src = vsrc + par * vpar;
+                const float *src = from_x ? xb + (t % kFwdSlots) * 32 : vsrc + par * L * KP;
+                float4 v4[KP / 4];
+#pragma unroll
+                for (int q = 0; q < KP / 4; ++q) v4[q] = *reinterpret_cast<const float4 *>(src + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);
+                flush();
+                __builtin_amdgcn_sched_barrier(0);
+                VSTAMP(0);
                 f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
 #pragma unroll
                 for (int q = 0; q < KP / 4; ++q) {
-                    const float4 v4 = *reinterpret_cast<const float4 *>(src + 4 * q);
-                    const f32x2 va = {v4.x, v4.y}, vb = {v4.z, v4.w};
+                    const f32x2 va = {v4[q].x, v4[q].y}, vb = {v4[q].z, v4[q].w};
                     acc0 = pk_fma(w[0][2 * q], va, acc0); acc1 = pk_fma(w[1][2 * q], va, acc1);
                     acc2 = pk_fma(w[2][2 * q], va, acc2);
                     acc0 = pk_fma(w[0][2 * q + 1], vb, acc0); acc1 = pk_fma(w[1][2 * q + 1], vb, acc1);
                     acc2 = pk_fma(w[2][2 * q + 1], vb, acc2);
                 }
                 float gi_r, gh_r, gi_z, gh_z, gi_n, gh_n;
+                VSTAMP(1);
                 both_halves(acc0.x + acc0.y, gi_r, gh_r);
                 both_halves(acc1.x + acc1.y, gi_z, gh_z);
                 both_halves(acc2.x + acc2.y, gi_n, gh_n);
@@ -217,22 +284,28 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
                 const float n = fast_tanh(gi_n + b_in + r * ghn);
                 const float hnew = n + z * (hreg - n);
                 if (active && unit) hreg = hnew;
-                const float yv = active ? hreg : 0.f;
                 if (p == 0 && j < KP) hw[(par ^ 1) * L * KP + j] = hreg;
+                VSTAMP(2);
                 // the two halves hold the same values: each stores half of them
                 const int oi = ((t * B + b) * H + j) * 4;
-                const int og = (unit && active) ? oi + (p ? 2 * tbh : 0) : kOOB;
-                buf_st(rs_gates, og, p ? n : r);                               // planes 0 (r) and 2 (n)
-                buf_st(rs_gates, og == kOOB ? kOOB : og + tbh, p ? ghn : z);   // planes 1 (z) and 3 (gh_n)
-                buf_st(rs_yint, (unit && p == 0) ? oi : kOOB, yv);
-                if (top) {
-                    const int er = ext_row(ym, t, b);
-                    buf_st(rs_yext, (unit && p == 1 && er >= 0) ? (er * H + j) * 4 : kOOB, yv);
-                }
-                if (t == len - 1) buf_st(rs_hn, (unit && p == 0) ? ((l * B + b) * H + j) * 4 : kOOB, yv);
+                q_y = active ? hreg : 0.f;
+                q_a = p ? n : r;
+                q_b = p ? ghn : z;
+                q_og = (unit && active) ? 4 * oi + 8 * p : kOOB;
+                q_oi = (unit && p == 0) ? oi : kOOB;
+                q_oe = (unit && p == 1) ? (ext_row(ym, t, b) * H + j) * 4 : kOOB;
+                q_last = t == len - 1;
+            } else {
+                flush();
+                q_og = q_oi = q_oe = kOOB;
+                q_last = false;
             }
+            VSTAMP(3);
             lds_barrier();
+            VSTAMP(4);
         }
+        flush();
+        VSTAMP_FLUSH
     }
 }
 
@@ -242,7 +315,7 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
 template <int KP>
 __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     using namespace vec;
-    // gv[L][4][KP] | dxb[2][L][KP] | ops[2][L][32][kOpsLd]
+    // gv[L][4][KP] | dxb[2][L][KP] | ops[kBwdSlots][kSlotFloats]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
@@ -255,81 +328,57 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     const int nticks = T + L - 1;
 
     if (l == L) {
-        // ---- loader: per layer and step  r z n gh_n | h_{t-1} | dy | layer input, kBwdRing ahead ----
-        // lower half: r, n, h_{t-1}, dy, input;  upper half: z, gh_n
+        // ---- loader (lower half of the wave): operands of every layer, kBwdAhead steps ahead --------
+        // At one tick layer q works on step t_q = T-1-tick+(L-1-q).  Per tick: the four saved gate
+        // values of every layer (one 16-byte load per unit), the layer outputs y_q[t_{q+1}] (each is
+        // both the input of layer q+1 and the previous state of layer q at this tick), the top
+        // layer's previous state, the stack input x and the incoming gradient dy; all of them go
+        // straight into LDS slot tick % kBwdSlots.  Straight-line code for kVecMaxL layers: a layer
+        // the stack does not have gets descriptors with zero records (zeros land in LDS).
         const ExtMap dym = ext_map_of(a.dymap), xm = ext_map_of(a.xmap);
+        __amdgpu_buffer_rsrc_t rs_g[kVecMaxL], rs_y[kVecMaxL];
+#pragma unroll
+        for (int q = 0; q < kVecMaxL; ++q) {
+            rs_g[q] = make_rsrc(q < L ? a.gates[q] : nullptr, 4L * tbh);
+            rs_y[q] = make_rsrc(q < L - 1 ? a.y_int[q] : nullptr, tbh);     // outputs feeding a layer above
+        }
+        const __amdgpu_buffer_rsrc_t rs_ytop = make_rsrc(a.y_int[L - 1], tbh);
         const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(a.dy_ext, tbh);
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
-        struct LOps { float g0, g1, hp, xin; };
+        const int gstep = B * H * 16, ystep = B * H * 4, xstep = xm.st * a.In * 4, dstep = dym.st * H * 4;
         for (int b = blockIdx.x; b < B; b += gridDim.x) {
             const int len = a.lengths ? a.lengths[b] : T;
-            LOps ring[kBwdRing][kSmallMaxL / 2];
-            float dyr[kBwdRing];
-            auto load_tick = [&](int k, LOps (&dst)[kSmallMaxL / 2], float &dy) {
-                dy = 0.f;
+            const int gbase = j < H ? (b * H + j) * 16 : kOOB;
+            const int ybase = j < H ? (b * H + j) * 4 : kOOB;
+            const int xbase = j < a.In ? (b * xm.sb * a.In + j) * 4 : kOOB;
+            const int dbase = j < H ? (b * dym.sb * H + j) * 4 : kOOB;
+            auto issue = [&](int k) {
+                if (p) return;
+                float *slot = ops + (k % kBwdSlots) * kSlotFloats;
+                const int t0 = T - 1 - k + (L - 1);          // step of layer 0; layer q works on t0 - q
 #pragma unroll
-                for (int q = 0; q < kSmallMaxL / 2; ++q) {
-                    if (q >= L) break;
-                    const int t = T - 1 - k + (L - 1 - q);
+                for (int q = 0; q < kVecMaxL; ++q) {
+                    const int t = t0 - q;
                     const bool ok = t >= 0 && t < len;
-                    const int In_q = q == 0 ? a.In : H;
-                    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gates[q], 4L * tbh);
-                    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y_int[q], tbh);
-                    const int oi = ((t * B + b) * H + j) * 4;
-                    const int og = (ok && j < H) ? oi + (p ? tbh : 0) : kOOB;
-                    dst[q].g0 = buf_ld(rs_g, og);                                  // r | z
-                    dst[q].g1 = buf_ld(rs_g, og == kOOB ? kOOB : og + 2 * tbh);    // n | gh_n
-                    dst[q].hp = buf_ld(rs_y, (ok && t > 0 && j < H && p == 0) ? oi - B * H * 4 : kOOB);
-                    if (q == 0) {
-                        int er = -1;
-                        if (ok) er = ext_row(xm, t, b);
-                        dst[q].xin = buf_ld(rs_x, (er >= 0 && j < In_q && p == 0) ? (er * In_q + j) * 4 : kOOB);
-                    } else {
-                        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.y_int[q - 1], tbh);
-                        dst[q].xin = buf_ld(rs_in, (ok && j < H && p == 0) ? oi : kOOB);
-                    }
-                    if (q == L - 1) {
-                        int er = -1;
-                        if (ok) er = ext_row(dym, t, b);
-                        dy = buf_ld(rs_dy, (er >= 0 && j < H && p == 0) ? (er * H + j) * 4 : kOOB);
-                    }
+                    lds_load_b128(rs_g[q], slot + kSlotG + q * 128, off_add(gbase, ok ? t * gstep : kOOB));
+                    // y_{q-1}[t]: input of layer q and previous state of layer q-1 at this tick
+                    if (q > 0) lds_load_b32(rs_y[q - 1], slot + kSlotY + (q - 1) * 32, off_add(ybase, ok ? t * ystep : kOOB));
                 }
+                const int tt = t0 - (L - 1);                  // step of the top layer
+                const bool okt = tt >= 0 && tt < len;
+                lds_load_b32(rs_ytop, slot + kSlotY + (kVecMaxL - 1) * 32, off_add(ybase, (okt && tt > 0) ? (tt - 1) * ystep : kOOB));
+                lds_load_b32(rs_x, slot + kSlotX, off_add(xbase, (t0 >= 0 && t0 < len) ? t0 * xstep : kOOB));
+                lds_load_b32(rs_dy, slot + kSlotD, off_add(dbase, okt ? tt * dstep : kOOB));
             };
-            auto hand_over = [&](int k, const LOps (&src)[kSmallMaxL / 2], float dy) {
-                float *dst = ops + (k & 1) * L * 32 * kOpsLd + j * kOpsLd;
-#pragma unroll
-                for (int q = 0; q < kSmallMaxL / 2; ++q) {
-                    if (q >= L) break;
-                    float *d = dst + q * 32 * kOpsLd;
-                    d[p] = src[q].g0;           // [0] r  [1] z
-                    d[2 + p] = src[q].g1;       // [2] n  [3] gh_n
-                    if (p == 0) {
-                        d[4] = src[q].hp;
-                        d[5] = (q == L - 1) ? dy : 0.f;
-                        d[6] = src[q].xin;
-                    }
-                }
-            };
-#pragma unroll
-            for (int u = 0; u < kBwdRing; ++u) load_tick(u == 0 ? kBwdRing : u, ring[u], dyr[u]);
-            {
-                LOps first[kSmallMaxL / 2];
-                float dy0;
-                load_tick(0, first, dy0);
-                hand_over(0, first, dy0);
-            }
+            for (int k = 0; k < kBwdAhead; ++k) issue(k);
+            wait_vmcnt<(kBwdAhead - 1) * kBwdLoads>();
             lds_barrier();
-            for (int k0 = 0; k0 < nticks; k0 += kBwdRing) {
-#pragma unroll
-                for (int u = 0; u < kBwdRing; ++u) {
-                    const int k = k0 + u;
-                    if (k >= nticks) break;
-                    const int un = (u + 1) % kBwdRing;
-                    hand_over(k + 1, ring[un], dyr[un]);
-                    load_tick(k + 1 + kBwdRing, ring[un], dyr[un]);
-                    lds_barrier();
-                }
+            for (int k = 0; k < nticks; ++k) {
+                issue(k + kBwdAhead);
+                wait_vmcnt<(kBwdAhead - 1) * kBwdLoads>();    // the operands of tick k+1 have landed
+                lds_barrier();
             }
+            wait_vmcnt<0>();                                  // the slots are reused by the next sequence
         }
         return;
     }
@@ -364,7 +413,6 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
 
     const __amdgpu_buffer_rsrc_t rs_dx = make_rsrc(l == 0 ? a.dx_ext : nullptr, (long)T * B * a.In * 4);
     const ExtMap dxm = ext_map_of(a.dxmap);
-    const float *myops = ops + (l * 32 + j) * kOpsLd;
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int len = a.lengths ? a.lengths[b] : T;
@@ -372,6 +420,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
         const long sb = ((long)l * B + b) * H + j;
         float dhc = (a.dh_n && unit) ? a.dh_n[sb] : 0.f;
         const float h0v = (a.h0 && unit) ? a.h0[sb] : 0.f;
+        wait_loads();
         lds_barrier();
 
         for (int k = 0; k < nticks; ++k) {
@@ -379,12 +428,12 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
             const int t = T - 1 - k + (L - 1 - l);
             if (t >= 0 && t < T) {
                 const bool active = t < len;
-                const float4 oa = *reinterpret_cast<const float4 *>(myops + par * L * 32 * kOpsLd);
-                const float4 ob = *reinterpret_cast<const float4 *>(myops + par * L * 32 * kOpsLd + 4);
+                const float *slot = ops + (k % kBwdSlots) * kSlotFloats;
+                const float4 oa = *reinterpret_cast<const float4 *>(slot + kSlotG + (l * 32 + j) * 4);
                 const float o_r = oa.x, o_z = oa.y, o_n = oa.z, o_hn = oa.w;
-                const float o_hp = (t == 0) ? h0v : ob.x;
-                const float o_xin = ob.z;
-                float dyv = ob.y;
+                const float o_hp = (t == 0) ? h0v : slot[kSlotY + (top ? kVecMaxL - 1 : l) * 32 + j];
+                const float o_xin = slot[(l == 0 ? kSlotX : kSlotY + (l - 1) * 32) + j];
+                float dyv = top ? slot[kSlotD + j] : 0.f;
                 if (!top && j < KP) dyv += dxb[((par ^ 1) * L + (l + 1)) * KP + j];
                 const bool on = active && unit;      // both halves run the gate arithmetic
                 const float d = on ? dyv + dhc : 0.f;
@@ -426,9 +475,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
                 if (l > 0) {
                     if (p == 0 && j < KP) dxb[(par * L + l) * KP + j] = dxv;
                 } else {
-                    int er = -1;
-                    if (active || !dxm.toff) er = ext_row(dxm, t, b);
-                    buf_st(rs_dx, (er >= 0 && p == 0 && j < a.In) ? (er * a.In + j) * 4 : kOOB, dxv);
+                    buf_st(rs_dx, (p == 0 && j < a.In) ? (ext_row(dxm, t, b) * a.In + j) * 4 : kOOB, dxv);
                 }
             }
             lds_barrier();
@@ -467,9 +514,9 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
 int gru_vec_workgroups(int B) { return B < 256 ? B : 256; }
 static int fwd_workgroups(int B) { return B < 512 ? B : 512; }
 
-// Up to 2048 sequences and 4 layers; byte offsets into every per-(t,b) buffer must fit 31 bits.
+// Up to 1024 sequences and 4 layers; byte offsets into every per-(t,b) buffer must fit 31 bits.
 bool gru_vec_supported(int B, int T, int In, int H, int L) {
-    if (H > 32 || In > 32 || L > 4 || B > 2048) return false;
+    if (H > 32 || In > 32 || L > vec::kVecMaxL || B > 1024) return false;
     const long widest = H > In ? H : In;
     return (long)T * B * widest * 16 < (1L << 31);
 }
@@ -478,7 +525,7 @@ hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
     dim3 grid(fwd_workgroups(a.B)), block(64 * (a.L + 1));
-    const size_t lds = (size_t)(2 * a.L + 2) * KP * sizeof(float);
+    const size_t lds = (size_t)(2 * a.L * KP + vec::kFwdSlots * 32) * sizeof(float);
     if (k24) hipLaunchKernelGGL(gru_vec_fwd_kernel<24>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(gru_vec_fwd_kernel<32>, grid, block, lds, s, a);
     return hipGetLastError();
@@ -488,7 +535,7 @@ hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
     dim3 grid(gru_vec_workgroups(a.B)), block(64 * (a.L + 1));
-    const size_t lds = (size_t)((4 * a.L + 2 * a.L) * KP + 2 * a.L * 32 * vec::kOpsLd) * sizeof(float);
+    const size_t lds = (size_t)((4 * a.L + 2 * a.L) * KP + vec::kBwdSlots * vec::kSlotFloats) * sizeof(float);
     if (k24) hipLaunchKernelGGL(gru_vec_bwd_kernel<24>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(gru_vec_bwd_kernel<32>, grid, block, lds, s, a);
     return hipGetLastError();

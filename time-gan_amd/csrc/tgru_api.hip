@@ -36,9 +36,10 @@ bool use_small(int In, int H, int L) {
     return !(e && e[0] == '1');
 }
 
-// Small stacks with up to 2048 sequences run one sequence per workgroup on the vector ALU
-// (gru_vec.hip); TGRU_NO_VEC=1 selects the MFMA whole-stack kernels for them instead.
-bool use_vec(int B, int T, int In, int H, int L) {
+// Small stacks with up to 1024 sequences in a padded layout run one sequence per workgroup on the
+// vector ALU (gru_vec.hip); TGRU_NO_VEC=1 selects the MFMA whole-stack kernels for them instead.
+bool use_vec(int B, int T, int In, int H, int L, int layout) {
+    if (layout == TGRU_LAYOUT_PACKED) return false;
     if (!use_small(In, H, L) || !gru_vec_supported(B, T, In, H, L)) return false;
     const char *e = getenv("TGRU_NO_VEC");
     return !(e && e[0] == '1');
@@ -215,7 +216,7 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         }
         f.h0 = h0; f.y_ext = y; f.ymap = ext_map(d, toff); f.h_n = h_n; f.lengths = lengths;
         f.B = B; f.T = T; f.H = H; f.L = L;
-        if (use_vec(B, T, In, H, L)) TGRU_HIP(launch_gru_vec_fwd(f, s));
+        if (use_vec(B, T, In, H, L, layout)) TGRU_HIP(launch_gru_vec_fwd(f, s));
         else TGRU_HIP(launch_gru_small_fwd(f, s));
         return TGRU_OK;
     }
@@ -303,7 +304,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp;
         g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
         g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(In, H, L);
-        if (use_vec(B, T, In, H, L)) {
+        if (use_vec(B, T, In, H, L, layout)) {
             // the backward kernel accumulates the weight gradients itself: one partial per workgroup
             b.x = x; b.xmap = ext_map(d, toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
             TGRU_HIP(launch_gru_vec_bwd(b, s));
