@@ -14,5 +14,5 @@ for _ in range(50): r.forward(x); r.backward(dy)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong*128)()
 _lib.lib().tgru_debug_stamps_vec.argtypes=[ctypes.c_void_p]; print('rc', _lib.lib().tgru_debug_stamps_vec(out))
-a = np.array(out[:]).reshape(16,8)[:6,:6]
-print('per wave cycles: [0 reads+flush, 1 fma, 2 gates, 3 bookkeeping, 4 barrier, 5 loop-top]'); print(a); print('per tick:', a.sum(1)/98, a/98)
+a = np.array(out[:]).reshape(16,8)[[0,1,2,8,9,10],:6]
+print('per wave cycles: [0 reads+flush, 1 fma, 2 gates, 3 bookkeeping, 4 barrier, 5 loop-top]'); np.set_printoptions(suppress=True, linewidth=200); print('fwd waves 0-2, bwd waves 0-2; per tick:'); print((a/98).round(0)); print('sum', (a.sum(1)/98).round(0))

@@ -46,7 +46,7 @@ __device__ unsigned long long tgru_stamps_vec[16 * 8];
     } while (0)
 #define VSTAMP_FLUSH                                                         \
     if (blockIdx.x == 0 && lane == 0)                                        \
-        for (int k_ = 0; k_ < 6; ++k_) tgru_stamps_vec[l * 8 + k_] = st_acc[k_];
+        for (int k_ = 0; k_ < 6; ++k_) tgru_stamps_vec[(l + VSTAMP_BASE) * 8 + k_] = st_acc[k_];
 extern "C" int tgru_debug_stamps_vec(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgru_stamps_vec), sizeof(unsigned long long) * 16 * 8);
 }
@@ -145,6 +145,7 @@ constexpr int kBwdLoads = 2 * kVecMaxL + 2;   // direct-to-LDS loads per step
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
+#define VSTAMP_BASE 0
 template <int KP>
 __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     using namespace vec;
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
 // ----------------------------------------------------------------------------------------------
 // backward (dx, dh0 and per-workgroup partial weight / bias gradients)
 // ----------------------------------------------------------------------------------------------
+#undef VSTAMP_BASE
+#define VSTAMP_BASE 8
 template <int KP>
 __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     using namespace vec;
@@ -423,9 +426,11 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
         wait_loads();
         lds_barrier();
 
+        VSTAMP_DECL
         for (int k = 0; k < nticks; ++k) {
             const int par = k & 1;
             const int t = T - 1 - k + (L - 1 - l);
+            VSTAMP(5);
             if (t >= 0 && t < T) {
                 const bool active = t < len;
                 const float *slot = ops + (k % kBwdSlots) * kSlotFloats;
@@ -449,26 +454,37 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
                     gv[(p ? 3 : 2) * KP + j] = p ? dgn : an;
                 }
                 dbs[0] += dar; dbs[1] += daz; dbs[2] += an; dbs[3] += dgn;
-                // rank-1 weight-gradient updates: rows from this half's dg, columns from its input
-                const float s = p ? o_hp : o_xin;
-                dWa[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(dar, s, dWa[0], 0, 0, 0);
-                dWa[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(daz, s, dWa[1], 0, 0, 0);
-                dWa[2] = __builtin_amdgcn_mfma_f32_32x32x1f32(p ? dgn : an, s, dWa[2], 0, 0, 0);
+                VSTAMP(0);
                 // same wave wrote the vectors: LDS executes a wave's accesses in order
+                VSTAMP(1);
                 f32x2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+                const float *g2 = gv + (p ? 3 : 2) * KP;
+                // rank-1 weight-gradient updates (rows from this half's dg, columns from its input):
+                // one MFMA every other block of the matrix-vector product below, so that no MFMA has
+                // to wait for the previous one and stall the instruction stream behind it
+                const float s = p ? o_hp : o_xin;
+                const float dg2 = p ? dgn : an;
 #pragma unroll
                 for (int q = 0; q < KP / 4; ++q) {
-                    const float4 u0 = *reinterpret_cast<const float4 *>(gv + 0 * KP + 4 * q);
-                    const float4 u1 = *reinterpret_cast<const float4 *>(gv + 1 * KP + 4 * q);
-                    const float4 u2 = *reinterpret_cast<const float4 *>(gv + (p ? 3 : 2) * KP + 4 * q);
-                    acc0 = pk_fma(wT[0][2 * q], (f32x2){u0.x, u0.y}, acc0);
-                    acc0 = pk_fma(wT[0][2 * q + 1], (f32x2){u0.z, u0.w}, acc0);
-                    acc1 = pk_fma(wT[1][2 * q], (f32x2){u1.x, u1.y}, acc1);
-                    acc1 = pk_fma(wT[1][2 * q + 1], (f32x2){u1.z, u1.w}, acc1);
-                    acc2 = pk_fma(wT[2][2 * q], (f32x2){u2.x, u2.y}, acc2);
-                    acc2 = pk_fma(wT[2][2 * q + 1], (f32x2){u2.z, u2.w}, acc2);
+                    const float4 v0 = *reinterpret_cast<const float4 *>(gv + 0 * KP + 4 * q);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(gv + 1 * KP + 4 * q);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(g2 + 4 * q);
+                    acc0 = pk_fma(wT[0][2 * q], (f32x2){v0.x, v0.y}, acc0);
+                    acc0 = pk_fma(wT[0][2 * q + 1], (f32x2){v0.z, v0.w}, acc0);
+                    acc1 = pk_fma(wT[1][2 * q], (f32x2){v1.x, v1.y}, acc1);
+                    acc1 = pk_fma(wT[1][2 * q + 1], (f32x2){v1.z, v1.w}, acc1);
+                    acc2 = pk_fma(wT[2][2 * q], (f32x2){v2.x, v2.y}, acc2);
+                    acc2 = pk_fma(wT[2][2 * q + 1], (f32x2){v2.z, v2.w}, acc2);
+                    if (q == 0 || q == 2 || q == 4) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q == 0) dWa[0] = __builtin_amdgcn_mfma_f32_32x32x1f32(dar, s, dWa[0], 0, 0, 0);
+                        if (q == 2) dWa[1] = __builtin_amdgcn_mfma_f32_32x32x1f32(daz, s, dWa[1], 0, 0, 0);
+                        if (q == 4) dWa[2] = __builtin_amdgcn_mfma_f32_32x32x1f32(dg2, s, dWa[2], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 const f32x2 sum = acc0 + acc1 + acc2;
+                VSTAMP(2);
                 float dxv, dhv;
                 both_halves(sum.x + sum.y, dxv, dhv);
                 dhc = keep + (on ? dhv : 0.f);
@@ -478,8 +494,11 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
                     buf_st(rs_dx, (p == 0 && j < a.In) ? (ext_row(dxm, t, b) * a.In + j) * 4 : kOOB, dxv);
                 }
             }
+            VSTAMP(3);
             lds_barrier();
+            VSTAMP(4);
         }
+        VSTAMP_FLUSH
         if (a.dh0 && p == 0 && unit) a.dh0[sb] = dhc;
     }
 
@@ -490,17 +509,19 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     long off = 0;
     for (int q = 0; q < l; ++q) off += 3L * H * ((q == 0 ? a.In : H) + H);
     float *slab = a.slabs + (long)blockIdx.x * a.slab_stride + off;
+    const __amdgpu_buffer_rsrc_t rs_slab = make_rsrc(slab, 3L * H * (In_l + H) * 4);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const int nc = blk ? H : In_l;
-        float *dst = slab + (blk ? 3L * H * In_l : 0);
+        const int lane_off = j < nc ? (blk ? 3 * H * In_l + j : j) * 4 : kOOB;   // column j of dW_ih / dW_hh
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int rr = 0; rr < 16; ++rr) {
+            const int i = 8 * (rr / 4) + (rr % 4) + 4 * p;                       // row inside the gate block
+            const int row_off = i < H ? i * nc * 4 : kOOB;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int i = 8 * (rr / 4) + (rr % 4) + 4 * p;
-                if (i < H && j < nc) dst[(long)(g * H + i) * nc + j] = dWa[g][16 * blk + rr];
-            }
+            for (int g = 0; g < 3; ++g)
+                buf_st(rs_slab, off_add(lane_off, row_off == kOOB ? kOOB : row_off + g * H * nc * 4), dWa[g][16 * blk + rr]);
+        }
     }
     if (p == 0 && unit) {
         float *dbp = a.db_part + ((long)blockIdx.x * L + l) * 4 * H;
