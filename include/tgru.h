@@ -128,6 +128,39 @@ int tgru_backward(const float *dy, const float *dh_n,
 int tgru_input_projection(const float *a, const float *w, const float *bias, float *out,
                           int M, int N, int K, tgru_stream_t stream);
 
+/*
+ * The dense "head" the reference puts before / after every GRU stack, fused over M independent rows:
+ *
+ *      y = [LayerNorm(din)] -> Linear(din -> dmid) -> [LayerNorm(dmid) -> ReLU -> Linear(dmid -> dout)]
+ *
+ * It replaces these torch module chains (outdated_files/TimeGANv1.py): the feature MLP in front of
+ * the embedder / generator GRU (:45-50,55 and :282-287,294), `norm` + `emb_linear` / `g_linear`
+ * behind it (:67-68, :305-306), `norm` + the 4-stage `mlp` of recovery and supervisor (:145-148,
+ * :226-227) and `norm` + Linear(H,1) of the discriminator (:382-383).  LayerNorm is torch's
+ * (biased variance, eps inside the square root).
+ *   ln0_w / ln0_b NULL: no input LayerNorm.   w2 NULL: shallow head, y = Linear1 output, dout == dmid.
+ *   x (M, din), y (M, dout) row-major; weights in torch layout (out_features, in_features).
+ *   Supported: din, dmid, dout <= 32 (TGRU_E_DIMS otherwise; callers keep the torch modules then).
+ *
+ * tgru_head_backward recomputes the forward from x, writes dx (may be NULL) and the parameter
+ * gradients into ONE flat buffer `dparams` of tgru_head_grad_floats() floats laid out as
+ *      dW1 (dmid*din) | db1 (dmid) | dln0_w (din) | dln0_b (din) | dln1_w (dmid) | dln1_b (dmid) |
+ *      dW2 (dout*dmid) | db2 (dout)
+ * (entries of absent stages are written as zeros).  `workspace` needs
+ * tgru_head_backward_workspace_bytes() bytes.  accumulate != 0 adds to dparams.
+ */
+size_t tgru_head_grad_floats(int din, int dmid, int dout);
+size_t tgru_head_backward_workspace_bytes(int M, int din, int dmid, int dout);
+int tgru_head_forward(const float *x, float *y, int M, int din, int dmid, int dout,
+                      const float *ln0_w, const float *ln0_b, const float *w1, const float *b1,
+                      const float *ln1_w, const float *ln1_b, const float *w2, const float *b2,
+                      float eps, tgru_stream_t stream);
+int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int din, int dmid, int dout,
+                       const float *ln0_w, const float *ln0_b, const float *w1, const float *b1,
+                       const float *ln1_w, const float *ln1_b, const float *w2, const float *b2,
+                       float eps, float *dparams, float *workspace, int accumulate,
+                       tgru_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,84 @@
+"""GPU tests of the fused dense head (tgru_head_forward / tgru_head_backward) against the torch
+modules it replaces (nn.LayerNorm / nn.Linear / ReLU evaluated on the CPU in fp32), for every head
+shape the five TimeGAN networks use and for ragged sizes."""
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import FWD_ATOL_SCALE, FWD_RTOL, GRAD_ATOL_SCALE, GRAD_RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+# (rows, din, dmid, dout, input LayerNorm, deep)
+CASES = [
+    (128 * 24, 6, 24, 24, False, True),     # embedder feature MLP (stock: 6 features)
+    (128 * 24, 24, 24, 24, True, False),    # norm + emb_linear / g_linear
+    (128 * 24, 24, 24, 6, True, True),      # recovery: norm + mlp(H -> H -> F)
+    (256 * 24, 24, 24, 24, True, True),     # supervisor on a doubled batch
+    (384 * 24, 24, 24, 1, True, False),     # discriminator: norm + Linear(H, 1)
+    (37, 5, 10, 7, True, True),             # ragged rows, widths that are not multiples of 4
+    (1, 32, 32, 32, True, True),            # a single row at the maximum width
+    (100, 28, 32, 32, False, False),
+]
+
+
+def _modules(din, dmid, dout, ln0, deep, seed):
+    torch.manual_seed(seed)
+    m = {"ln0": nn.LayerNorm(din) if ln0 else None, "lin1": nn.Linear(din, dmid),
+         "ln1": nn.LayerNorm(dmid) if deep else None, "lin2": nn.Linear(dmid, dout) if deep else None}
+    for k in ("ln0", "ln1"):   # non-trivial affine parameters
+        if m[k] is not None:
+            with torch.no_grad():
+                m[k].weight.uniform_(0.5, 1.5)
+                m[k].bias.uniform_(-0.5, 0.5)
+    return m
+
+
+def _torch_head(m, x):
+    h = m["lin1"](x if m["ln0"] is None else m["ln0"](x))
+    return h if m["lin2"] is None else m["lin2"](torch.relu(m["ln1"](h)))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "m%d_%d_%d_%d_ln%d_deep%d" % c)
+@pytest.mark.parametrize("want_dx", [True, False])
+def test_head_matches_torch(case, want_dx):
+    import copy
+    from timegan_amd.head import head_apply, supported
+    M, din, dmid, dout, ln0, deep = case
+    ref = _modules(din, dmid, dout, ln0, deep, seed=M + din)
+    ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, din, generator=g)
+    dy = torch.randn(M, dout, generator=g)
+    xr = x.clone().requires_grad_(want_dx)
+    xo = x.clone().to("cuda:0").requires_grad_(want_dx)
+    assert supported(xo, ours["lin1"], ours["lin2"])
+    yr = _torch_head(ref, xr)
+    yo = head_apply(xo, ours["ln0"], ours["lin1"], ours["ln1"], ours["lin2"])
+    (yr * dy).sum().backward()
+    (yo * dy.cuda()).sum().backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    if want_dx:
+        assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    for k in ref:
+        if ref[k] is None:
+            continue
+        for (name, pr), (_, po) in zip(ref[k].named_parameters(), ours[k].named_parameters()):
+            assert_close(po.grad.cpu().numpy(), pr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"d{k}.{name}")
+
+
+def test_head_3d_input_and_wide_fallback():
+    """(B, T, F) inputs keep their leading shape; widths above 32 run the torch modules on the GPU."""
+    from timegan_amd.head import head_apply, supported
+    m = _modules(6, 48, 24, False, True, seed=0)
+    m = {k: (None if v is None else v.to("cuda:0")) for k, v in m.items()}
+    x = torch.rand(4, 5, 6, device="cuda:0")
+    assert not supported(x, m["lin1"], m["lin2"])
+    y = head_apply(x, None, m["lin1"], m["ln1"], m["lin2"])
+    assert y.shape == (4, 5, 24)
+    m2 = _modules(6, 24, 24, False, True, seed=0)
+    m2 = {k: (None if v is None else v.to("cuda:0")) for k, v in m2.items()}
+    y2 = head_apply(x, None, m2["lin1"], m2["ln1"], m2["lin2"])
+    ref = _torch_head({k: (None if v is None else v.cpu()) for k, v in m2.items()}, x.cpu())
+    assert y2.shape == (4, 5, 24)
+    assert_close(y2.detach().cpu().numpy(), ref.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y 3d")

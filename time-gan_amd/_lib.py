@@ -27,6 +27,10 @@ SIGNATURES = {
     "tgru_forward": (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
     "tgru_backward": (_i, [_vp] * 19 + [_i] * 7 + [_vp]),
     "tgru_input_projection": (_i, [_vp] * 4 + [_i] * 3 + [_vp]),
+    "tgru_head_grad_floats": (ctypes.c_size_t, [_i] * 3),
+    "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),
+    "tgru_head_forward": (_i, [_vp] * 2 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp]),
+    "tgru_head_backward": (_i, [_vp] * 3 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp, _vp, _i, _vp]),
 }
 
 

@@ -1,0 +1,111 @@
+"""Fused dense head of the TimeGAN networks on the GPU (libtgru.so: tgru_head_forward/backward).
+
+    y = [LayerNorm] -> Linear -> [LayerNorm -> ReLU -> Linear]        (per row, widths <= 32)
+
+The op takes the parameters of ordinary torch modules (nn.LayerNorm, nn.Linear), so the networks
+keep torch's module structure and state_dict keys (outdated_files/TimeGANv1.py:39-50,119-128,
+198-207,276-287,355-357); only their forward goes through one kernel instead of 5-8, and their
+backward through two instead of about twenty.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib
+
+MAX_WIDTH = 32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _HeadFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, g0, b0, w1, c1, g1, b1, w2, c2):
+        din = x.shape[-1]
+        dmid = w1.shape[0]
+        dout = dmid if w2 is None else w2.shape[0]
+        x2 = x.contiguous().view(-1, din)
+        M = x2.shape[0]
+        params = [None if p is None else p.contiguous() for p in (g0, b0, w1, c1, g1, b1, w2, c2)]
+        y = torch.empty(x.shape[:-1] + (dout,), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            check(lib().tgru_head_forward(_ptr(x2), _ptr(y), M, din, dmid, dout, *[_ptr(p) for p in params],
+                                          float(eps), _stream(x.device)), "tgru_head_forward")
+        ctx.dims = (M, din, dmid, dout, float(eps))
+        ctx.save_for_backward(x2, *[p for p in params if p is not None])
+        ctx.present = [p is not None for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, din, dmid, dout, eps = ctx.dims
+        saved = list(ctx.saved_tensors)
+        x2 = saved.pop(0)
+        params = [saved.pop(0) if pres else None for pres in ctx.present]
+        g0, b0, w1, c1, g1, b1, w2, c2 = params
+        dev = x2.device
+        dy2 = dy.contiguous().view(-1, dout)
+        with torch.cuda.device(dev):
+            lb = lib()
+            n = lb.tgru_head_grad_floats(din, dmid, dout)
+            dparams = torch.empty(n, device=dev, dtype=torch.float32)
+            ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
+                             dtype=torch.float32)
+            dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+            check(lb.tgru_head_backward(_ptr(x2), _ptr(dy2), _ptr(dx), M, din, dmid, dout,
+                                        *[_ptr(p) for p in params], eps, _ptr(dparams), _ptr(ws), 0,
+                                        _stream(dev)), "tgru_head_backward")
+        o = 0
+
+        def take(cnt, shape, present):
+            nonlocal o
+            v = dparams[o:o + cnt].view(shape) if present else None
+            o += cnt
+            return v
+        dw1 = take(dmid * din, (dmid, din), True)
+        dc1 = take(dmid, (dmid,), True)
+        dg0 = take(din, (din,), g0 is not None)
+        db0 = take(din, (din,), b0 is not None)
+        dg1 = take(dmid, (dmid,), g1 is not None)
+        db1 = take(dmid, (dmid,), b1 is not None)
+        dw2 = take(dout * dmid, (dout, dmid), w2 is not None)
+        dc2 = take(dout, (dout,), c2 is not None)
+        if dx is not None:
+            dx = dx.view(dy.shape[:-1] + (din,))
+        return (dx, None, dg0, db0, dw1, dc1, dg1, db1, dw2, dc2)
+
+
+def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear]) -> bool:
+    """True when the fused kernels cover this head: GPU fp32 rows, every width <= 32, biases present."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        return False
+    widths = [lin1.in_features, lin1.out_features] + ([lin2.out_features] if lin2 is not None else [])
+    if max(widths) > MAX_WIDTH or lin1.bias is None or (lin2 is not None and lin2.bias is None):
+        return False
+    return True
+
+
+def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
+               ln1: Optional[nn.LayerNorm] = None, lin2: Optional[nn.Linear] = None) -> torch.Tensor:
+    """lin2(relu(ln1(lin1(ln0(x))))) with the optional stages as given; torch modules when the fused
+    kernels do not cover the widths (still on the GPU)."""
+    assert (ln1 is None) == (lin2 is None)
+    if not supported(x, lin1, lin2):
+        h = lin1(x if ln0 is None else ln0(x))
+        return h if lin2 is None else lin2(torch.relu(ln1(h)))
+    eps = (ln0 or ln1).eps if (ln0 is not None or ln1 is not None) else 1e-5
+    if ln0 is not None and ln1 is not None:
+        assert ln0.eps == ln1.eps
+    return _HeadFunction.apply(x, eps,
+                               None if ln0 is None else ln0.weight, None if ln0 is None else ln0.bias,
+                               lin1.weight, lin1.bias,
+                               None if ln1 is None else ln1.weight, None if ln1 is None else ln1.bias,
+                               None if lin2 is None else lin2.weight, None if lin2 is None else lin2.bias)

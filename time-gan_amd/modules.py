@@ -6,6 +6,8 @@ creation order (so state_dict keys, shapes and same-seed initial values match th
 
 Differences, all output-preserving:
   * the recurrent layer is `timegan_amd.GRU` (HIP kernels) instead of torch.nn.GRU;
+  * the dense stages around it (LayerNorm / Linear / ReLU chains) run as one fused kernel each
+    (`head.py`) when every width is <= 32, through the very same torch parameters;
   * pack_padded_sequence / pad_packed_sequence (TimeGANv1.py:56-65) are not materialised: lengths go
     to the kernels, which skip finished sequences and write the padding rows themselves.
 
@@ -18,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .gru import GRU
+from .head import head_apply
 
 
 class _RecurrentBlock(nn.Module):
@@ -36,6 +39,16 @@ class _RecurrentBlock(nn.Module):
         h, _ = nn.utils.rnn.pad_packed_sequence(sequence=h, batch_first=True,
                                                 padding_value=self.padding_value, total_length=self.seq_len)
         return h
+
+    def _head(self, x: torch.Tensor, ln0, lin1, mlp=None) -> torch.Tensor:
+        """[ln0] -> lin1 -> [mlp = (LayerNorm, ReLU, Linear)]: one fused kernel on the GPU path, the torch
+        modules themselves on the CPU path (`rnn_cls=torch.nn.GRU`)."""
+        if x.is_cuda and isinstance(getattr(self, self._rnn_name), GRU):
+            if mlp is None:
+                return head_apply(x, ln0, lin1)
+            return head_apply(x, ln0, lin1, mlp[0], mlp[2])
+        h = lin1(x if ln0 is None else ln0(x))
+        return h if mlp is None else mlp[2](mlp[1](mlp[0](h)))
 
     @property
     def device(self):
@@ -59,9 +72,11 @@ class Embedding(_RecurrentBlock):
         self.mlp = nn.Sequential(nn.Linear(self.dim_features, self.dim_hidden), nn.LayerNorm(self.dim_hidden),
                                  nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_hidden))
 
+    _rnn_name = "emb_rnn"
+
     def forward(self, x: torch.Tensor, t) -> torch.Tensor:
-        h = self._run_rnn(self.emb_rnn, self.mlp(x), t)
-        return self.emb_linear(self.norm(h))
+        h = self._run_rnn(self.emb_rnn, self._head(x, None, self.mlp[0], self.mlp[1:]), t)
+        return self._head(h, self.norm, self.emb_linear)
 
 
 class Recovery(_RecurrentBlock):
@@ -80,8 +95,10 @@ class Recovery(_RecurrentBlock):
                                  nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_output))
         self.norm = nn.LayerNorm(self.dim_hidden)
 
+    _rnn_name = "rec_rnn"
+
     def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self.mlp(self.norm(self._run_rnn(self.rec_rnn, h, t)))
+        return self._head(self._run_rnn(self.rec_rnn, h, t), self.norm, self.mlp[0], self.mlp[1:])
 
 
 class Supervisor(_RecurrentBlock):
@@ -99,8 +116,10 @@ class Supervisor(_RecurrentBlock):
                                  nn.ReLU(), nn.Linear(self.dim_hidden, self.dim_hidden))
         self.norm = nn.LayerNorm(self.dim_hidden)
 
+    _rnn_name = "sup_rnn"
+
     def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self.mlp(self.norm(self._run_rnn(self.sup_rnn, h, t)))
+        return self._head(self._run_rnn(self.sup_rnn, h, t), self.norm, self.mlp[0], self.mlp[1:])
 
 
 class Generator(_RecurrentBlock):
@@ -120,9 +139,11 @@ class Generator(_RecurrentBlock):
                                  nn.ReLU(), nn.Linear(self.dim_hidden * 2, self.dim_hidden))
         self.norm = nn.LayerNorm(self.dim_hidden)
 
+    _rnn_name = "g_rnn"
+
     def forward(self, z: torch.Tensor, t) -> torch.Tensor:
-        h = self._run_rnn(self.g_rnn, self.mlp(z), t)
-        return self.g_linear(self.norm(h))
+        h = self._run_rnn(self.g_rnn, self._head(z, None, self.mlp[0], self.mlp[1:]), t)
+        return self._head(h, self.norm, self.g_linear)
 
 
 class Discriminator(_RecurrentBlock):
@@ -139,8 +160,10 @@ class Discriminator(_RecurrentBlock):
         self.norm = nn.LayerNorm(self.dim_hidden)
         self.mlp = nn.Sequential(nn.Linear(self.dim_hidden, 1))
 
+    _rnn_name = "d_rnn"
+
     def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self.mlp(self.norm(self._run_rnn(self.d_rnn, h, t)))
+        return self._head(self._run_rnn(self.d_rnn, h, t), self.norm, self.mlp[0])
 
 
 def build_networks(cfg: Dict, rnn_cls=GRU) -> Dict[str, nn.Module]:
