@@ -55,6 +55,11 @@ def _compare_run(ref, ours, x, lengths, packed, tag):
     (20, 6, 28, 256, 1, None),                        # scorer shape: In 28 -> H 256, one layer
     (17, 5, 100, 100, 2, [5, 5, 5, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1, 1, 1, 1]),   # H=100: odd tile count
     (16, 4, 64, 512, 2, None),                        # C4 sizes, small batch (W_hh streamed from L2)
+    (300, 12, 24, 24, 3, None),                       # one-sequence-per-workgroup kernels, backward workgroups loop over 2 sequences
+    (600, 5, 6, 24, 2, [5] * 200 + [4] * 200 + [2] * 200),   # ... forward workgroups loop too; lengths; In != H
+    (33, 9, 28, 32, 4, None),                         # ... 32-wide variant, 4 layers
+    (7, 6, 30, 30, 1, [6, 6, 5, 3, 3, 2, 1]),         # ... widths that are not multiples of 4, one layer
+    (1100, 4, 24, 24, 3, None),                       # above 1024 sequences: MFMA whole-stack kernels
 ])
 def test_dropin_module_matches_torch_cpu(B, T, In, H, L, lengths, packed):
     ref, ours = _pair(In, H, L)
