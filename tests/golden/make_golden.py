@@ -13,6 +13,8 @@ copied.  Two sources are used:
   * module / loss / step level (modules_c1.npz, losses_c1.npz, steps_c1.npz): the reference's own
     classes and functions, imported from --ref with `wandb` (a logging service that is not
     installed) and the plotting call stubbed out.
+  * data level (scorer_split.npz): the reference's SineWave and Energy dataset classes on a seeded
+    draw / a small synthetic table, and the scorer's 75/25 split of that data.
 """
 import argparse
 import os
@@ -348,10 +350,56 @@ def make_step_fixtures(R):
     print(f"steps_c1: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_data_fixtures(ref):
+    """F5: the reference's data classes (data/SineWave.py, data/Energy.py) on a seeded draw and a
+    small synthetic table, and the arrays of the 75/25 split that metrics/discriminative.py:57-78
+    builds from them (that script cannot run as a whole -- it needs trained checkpoints -- so the
+    split is taken with the same index expressions on the reference-generated data)."""
+    import tempfile
+    sys.path.insert(0, ref)
+    from data import SineWave, Energy
+    out = {}
+    np.random.seed(7)
+    ds = SineWave.SineWave(samples_number=40, seq_len=24, features_dim=6)
+    real = np.asarray(ds.get_distribution())
+    out["sine.seed"] = np.array(7)
+    out["sine.data"] = real
+    rng = np.random.RandomState(11)
+    table = rng.rand(60, 4) * np.array([1.0, 10.0, 100.0, 0.5]) + np.array([0.0, -3.0, 50.0, 2.0])
+    with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as f:
+        f.write("a,b,c,d\n")
+        for row in table:
+            f.write(",".join(repr(float(v)) for v in row) + "\n")
+        path = f.name
+    en = Energy.Energy(seq_len=24, path=path)
+    os.unlink(path)
+    out["table"] = table
+    out["energy.windows"] = np.asarray(en.get_distribution())
+    t, msl = Energy.extract_time(np.asarray(en.get_distribution())[:5])
+    out["energy.time"] = np.array(t)
+    out["energy.max_seq_len"] = np.array(msl)
+    # the split (discriminative.py:57-78) on real = sine data, synthetic = a seeded stand-in
+    sd = np.random.RandomState(5).rand(*real.shape)
+    n_events = len(real)
+    idx = np.arange(n_events)
+    n_train = int(.75 * n_events)
+    train_idx, test_idx = idx[:n_train], idx[n_train:]
+    out["split.synth"] = sd
+    out["split.X_stock_train"] = real[train_idx, :24, :]
+    out["split.X_synth_train"] = sd[train_idx, :24, :]
+    out["split.X_stock_test"] = real[test_idx, :24, :]
+    out["split.y_stock_test"] = real[test_idx, -1, :]
+    out["split.y_stock_train"] = real[train_idx, -1, :]
+    out["split.y_synth_train"] = sd[train_idx, -1, :]
+    path = os.path.join(HERE, "scorer_split.npz")
+    np.savez_compressed(path, **out)
+    print(f"scorer_split: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="all", choices=["all", "gru", "ref"])
+    ap.add_argument("--only", default="all", choices=["all", "gru", "ref", "data"])
     args = ap.parse_args()
     torch.set_num_threads(1)
     if args.only in ("all", "gru"):
@@ -361,3 +409,5 @@ if __name__ == "__main__":
         make_module_fixtures(R)
         make_loss_fixtures(R)
         make_step_fixtures(R)
+    if args.only in ("all", "data"):
+        make_data_fixtures(args.ref)

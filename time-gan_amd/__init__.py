@@ -4,5 +4,6 @@ from .functional import GRURunner, gru_forward_backward_raw, gru_apply, input_pr
 from .gru import GRU  # noqa: F401
 from .modules import (Embedding, Recovery, Supervisor, Generator, Discriminator,  # noqa: F401
                       build_networks, make_cfg)
-from . import losses, parallel  # noqa: F401
+from . import data, losses, parallel, scorer  # noqa: F401
+from .head import head_apply  # noqa: F401
 from .trainer import TimeGANTrainer  # noqa: F401

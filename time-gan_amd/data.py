@@ -1,0 +1,77 @@
+"""Data side of the TimeGAN path, host mirrors of data/SineWave.py, data/Energy.py and data/Stock.py.
+
+The reference builds Python lists of per-sample arrays and feeds them through a DataLoader with ten
+worker processes; here a dataset is ONE array (numpy on the host, or a tensor resident in HBM) and a
+batch is a slice of it, so the input pipeline cannot cap the iteration rate.
+"""
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def min_max_scale(data: np.ndarray) -> np.ndarray:
+    """MinMaxScaler of data/Energy.py:5-9 (per column, 1e-7 in the denominator)."""
+    lo = np.min(data, 0)
+    return (data - lo) / (np.max(data, 0) - lo + 1e-7)
+
+
+def sliding_windows(table: np.ndarray, seq_len: int) -> np.ndarray:
+    """The window construction of Energy / Stock (data/Energy.py:25-31): reverse the rows, scale,
+    then every window [i, i + seq_len) for i < len - seq_len.  Returns (N, seq_len, F)."""
+    scaled = min_max_scale(np.asarray(table)[::-1])
+    n = len(scaled) - seq_len
+    if n <= 0:
+        return np.empty((0, seq_len, scaled.shape[1]), dtype=scaled.dtype)
+    idx = np.arange(n)[:, None] + np.arange(seq_len)[None, :]
+    return scaled[idx]
+
+
+def load_csv_windows(path: str, seq_len: int) -> np.ndarray:
+    """Energy(seq_len, path) / Stock(seq_len, path): a CSV with one header row."""
+    return sliding_windows(np.loadtxt(path, delimiter=",", skiprows=1), seq_len)
+
+
+def sine_wave(samples_number: int, seq_len: int, features_dim: int,
+              rng: Optional[np.random.RandomState] = None) -> np.ndarray:
+    """SineWave(samples_number, seq_len, features_dim).get_distribution() as one (N, T, F) array
+    (data/SineWave.py:5-25): per sample and feature a frequency and a phase from U(0, 0.1) -- drawn
+    in the reference's order, so the same legacy seed gives the same data -- then
+    (sin(freq * j + phase) + 1) / 2."""
+    rng = np.random if rng is None else rng
+    fp = rng.uniform(0, 0.1, size=(samples_number, features_dim, 2))
+    j = np.arange(seq_len, dtype=np.float64)[None, :, None]
+    freq = fp[:, None, :, 0]
+    phase = fp[:, None, :, 1]
+    return (np.sin(freq * j + phase) + 1) * 0.5
+
+
+def extract_time(data) -> Tuple[List[int], int]:
+    """extract_time of data/Energy.py:12-19 for a dense batch: every length is the time dimension."""
+    n, t = int(data.shape[0]), int(data.shape[1])
+    return [t] * n, t
+
+
+class ResidentDataset:
+    """A dataset held as one float32 tensor on the device; batches are index gathers in HBM."""
+
+    def __init__(self, samples, device):
+        self.data = torch.as_tensor(np.asarray(samples), dtype=torch.float32).to(device)
+
+    def __len__(self) -> int:
+        return int(self.data.shape[0])
+
+    def batches(self, batch_size: int, shuffle: bool = True, generator: Optional[torch.Generator] = None,
+                rank: int = 0, world: int = 1) -> Iterator[torch.Tensor]:
+        """Batches of one epoch; with `world` > 1 every rank takes its contiguous shard of each global
+        batch (the same permutation must be drawn on every rank: pass identically seeded generators)."""
+        n = len(self)
+        order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        order = order.to(self.data.device)
+        for s in range(0, n, batch_size):
+            idx = order[s:s + batch_size]
+            if world > 1:
+                per = (idx.numel() + world - 1) // world
+                idx = idx[rank * per:(rank + 1) * per]
+            if idx.numel():
+                yield self.data.index_select(0, idx)
