@@ -1,0 +1,214 @@
+// Per-layer recurrent kernels for mid-size hidden states, 32 < H <= 128 (H % 4 == 0): the energy
+// config's H = 96.
+//
+// A 16-column MFMA tile needs 16 sequences per workgroup: a batch of 1024 then occupies 64 of the 256
+// CUs.  These kernels take FOUR sequences per workgroup (256 workgroups at B = 1024) and use
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per instruction, at the same
+// MAC rate as the large tiles.  Lane 4b+i supplies A_b[i], lane 4b+j supplies B_b[j], and register i
+// of lane 4b+j receives D_b[i][j] += A_b[i] * B_b[j].  With
+//      A_b[i] = W[64*wave + 4b + i][k]   (one weight-matrix row per lane, the row lives in VGPRs)
+//      B_b[j] = v[k][j]                  (the step's vector of sequence j, the same in every block)
+// one instruction per k accumulates a 64-row x 4-sequence slice of W . v, and a wave never touches
+// memory for its weights.  Per step: MFMA phase (rows spread over ceil(3H/64) waves) -> results to
+// LDS -> barrier -> gate phase ((unit, sequence) pairs spread over all threads) -> new state to LDS
+// -> barrier.  The operands that come from global memory (the precomputed input projection gi of
+// the step in forward; saved gates and incoming gradients in backward) are fetched several steps
+// ahead by a loader wave with direct-to-LDS loads, so compute waves only ever store.
+#include "tgru_internal.h"
+
+namespace tgru {
+namespace mid {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSeq = 4;            // sequences per workgroup
+constexpr int kAhead = 4;          // steps the loader runs ahead
+constexpr int kSlots = kAhead + 1;
+constexpr int kOOB = 0x7ffffff0;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+__device__ __forceinline__ void wait_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void lds_load_b128(__amdgpu_buffer_rsrc_t r, float *lds, int off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, off, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace mid
+
+// ----------------------------------------------------------------------------------------------
+// forward: h_t from gi_t (input projection incl. b_ih, precomputed for all steps) and h_{t-1}
+// ----------------------------------------------------------------------------------------------
+template <int HP>
+__global__ __launch_bounds__(448) void gru_mid_fwd_kernel(FwdArgs a) {
+    using namespace mid;
+    constexpr int NI = (3 * HP + 63) / 64;        // 16-byte direct-to-LDS loads per step (4 rows of 3H floats)
+    // hs[2][kSeq][HP] | ghs[kSeq][GS] | gis[kSlots][NI*256]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, B = a.B, T = a.T;
+    const int nw = (3 * H + 63) / 64;             // compute waves; wave nw is the loader
+    const int GS = nw * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *hs = smem;
+    float *ghs = hs + 2 * kSeq * HP;
+    float *gis = ghs + kSeq * GS;
+    const int b0 = blockIdx.x * kSeq;
+
+    if (wave == nw) {
+        // ---- loader: gi rows of the workgroup's four sequences, flattened [seq][3H], kAhead steps ahead --
+        const __amdgpu_buffer_rsrc_t rs_gi = make_rsrc(a.gi, (long)T * B * 3 * H * 4);
+        auto issue = [&](int t) {
+            float *slot = gis + (t % kSlots) * NI * 256;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = (i * 64 + lane) * 4;              // element of the flattened [kSeq][3H] block
+                const int j = e / (3 * H), off = e - j * 3 * H;
+                const bool ok = t < T && j < kSeq && b0 + j < B;
+                lds_load_b128(rs_gi, slot + i * 256, ok ? (((t * B + b0 + j) * 3 * H) + off) * 4 : kOOB);
+            }
+        };
+        for (int t = 0; t < kAhead; ++t) issue(t);
+        wait_vmcnt<(kAhead - 1) * NI>();
+        lds_barrier();
+        for (int t = 0; t < T; ++t) {
+            issue(t + kAhead);
+            lds_barrier();                        // A: end of the MFMA phase
+            wait_vmcnt<(kAhead - 1) * NI>();      // gi of step t+1 has landed
+            lds_barrier();                        // B: end of the gate phase
+        }
+        wait_vmcnt<0>();
+        return;
+    }
+
+    // ---- one row of W_hh per lane ------------------------------------------------------------------
+    const int row = wave * 64 + lane;
+    float w[HP];
+    {
+        const bool ok = row < 3 * H;
+        const float *src = a.w_hh + (long)row * H;
+#pragma unroll
+        for (int q = 0; q < HP / 4; ++q) {
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && 4 * q < H) u = *reinterpret_cast<const float4 *>(src + 4 * q);
+            w[4 * q] = u.x; w[4 * q + 1] = u.y; w[4 * q + 2] = u.z; w[4 * q + 3] = u.w;
+        }
+    }
+    // ---- gate phase: (sequence, unit) pairs p = j*H + u of this thread -------------------------------
+    const int nthreads = nw * 64;
+    const int tid = threadIdx.x;
+    constexpr int kPairs = 2;                     // 4*H pairs over >= 3*H threads
+    int pj[kPairs], pu[kPairs], plen[kPairs];
+    float bh_r[kPairs], bh_z[kPairs], bh_n[kPairs];
+    bool pok[kPairs];
+#pragma unroll
+    for (int s = 0; s < kPairs; ++s) {
+        const int p = tid + s * nthreads;
+        const bool in = p < kSeq * H;
+        pj[s] = in ? p / H : 0;
+        pu[s] = in ? p % H : 0;
+        pok[s] = in && b0 + pj[s] < B;            // a real sequence (the last workgroup may have fewer than four)
+        plen[s] = pok[s] ? (a.lengths ? a.lengths[b0 + pj[s]] : T) : 0;
+        bh_r[s] = a.b_hh[pu[s]];
+        bh_z[s] = a.b_hh[H + pu[s]];
+        bh_n[s] = a.b_hh[2 * H + pu[s]];
+        const float h0v = (pok[s] && a.h0) ? a.h0[(long)(b0 + pj[s]) * H + pu[s]] : 0.f;
+        if (p < kSeq * H) {
+            hs[(0 * kSeq + p / H) * HP + p % H] = h0v;
+            hs[(1 * kSeq + p / H) * HP + p % H] = h0v;
+        }
+    }
+    // zero the padding of the state vectors (units H..HP-1)
+    for (int i = tid; i < 2 * kSeq * (HP - H); i += nthreads) {
+        const int v = i / (HP - H), c = i % (HP - H);
+        hs[v * HP + H + c] = 0.f;
+    }
+    const long plane = (long)T * B * H;
+    const int ysb = a.ymap.mode == 1 ? T : 1, yst = a.ymap.mode == 1 ? 1 : B;
+    const int jl = lane & 3, bl = lane >> 2;
+    wait_loads();
+    lds_barrier();
+
+    for (int t = 0; t < T; ++t) {
+        const int par = t & 1;
+        // ---- MFMA phase: gh[row][j] = sum_k W_hh[row][k] * h[j][k] -------------------------------
+        {
+            const float *hv = hs + (par * kSeq + jl) * HP;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int q = 0; q < HP / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(hv + 4 * q);
+                acc0 = mfma4(w[4 * q], v.x, acc0);
+                acc1 = mfma4(w[4 * q + 1], v.y, acc1);
+                acc0 = mfma4(w[4 * q + 2], v.z, acc0);
+                acc1 = mfma4(w[4 * q + 3], v.w, acc1);
+            }
+            mfma_drain();
+            // lane 4b+j holds rows 64*wave + 4b .. +3 of sequence j
+            *reinterpret_cast<float4 *>(ghs + jl * GS + wave * 64 + 4 * bl) =
+                make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+        }
+        lds_barrier();   // A
+        // ---- gate phase ----------------------------------------------------------------------------
+        const float *gi = gis + (t % kSlots) * NI * 256;
+#pragma unroll
+        for (int s = 0; s < kPairs; ++s) {
+            if (tid + s * nthreads < kSeq * H) {
+                const int j = pj[s], u = pu[s];
+                const float *g = ghs + j * GS;
+                const float *x = gi + j * 3 * H;
+                const float r = fast_sigmoid(x[u] + g[u] + bh_r[s]);
+                const float z = fast_sigmoid(x[H + u] + g[H + u] + bh_z[s]);
+                const float ghn = g[2 * H + u] + bh_n[s];
+                const float n = fast_tanh(x[2 * H + u] + r * ghn);
+                const float hp = hs[(par * kSeq + j) * HP + u];
+                const bool active = t < plen[s];
+                const float h = active ? n + z * (hp - n) : hp;
+                hs[((par ^ 1) * kSeq + j) * HP + u] = h;
+                if (pok[s]) {
+                    const float yv = active ? h : 0.f;
+                    const long rowi = ((long)t * B + b0 + j) * H + u;
+                    if (a.y_int) a.y_int[rowi] = yv;
+                    if (a.y_ext) {
+                        const long er = a.ymap.mode == 2 ? map_tb(a.ymap, t, b0 + j) : (long)t * yst + (long)(b0 + j) * ysb;
+                        if (er >= 0) a.y_ext[er * H + u] = yv;
+                    }
+                    if (a.gates && active) {
+                        a.gates[rowi] = r;
+                        a.gates[plane + rowi] = z;
+                        a.gates[2 * plane + rowi] = n;
+                        a.gates[3 * plane + rowi] = ghn;
+                    }
+                    if (a.h_n && t == plen[s] - 1) a.h_n[(long)(b0 + j) * H + u] = yv;
+                }
+            }
+        }
+        lds_barrier();   // B
+    }
+}
+
+bool gru_mid_supported(int H) { return H > 32 && H <= 128 && (H & 3) == 0; }
+
+hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s) {
+    const int nw = (3 * a.H + 63) / 64;
+    dim3 grid((a.B + mid::kSeq - 1) / mid::kSeq), block(64 * (nw + 1));
+    const int HP = a.H <= 64 ? 64 : (a.H <= 96 ? 96 : 128);
+    const int NI = (3 * HP + 63) / 64;
+    const size_t lds = (size_t)(2 * mid::kSeq * HP + mid::kSeq * nw * 64 + mid::kSlots * NI * 256) * sizeof(float);
+    if (HP == 64) hipLaunchKernelGGL(gru_mid_fwd_kernel<64>, grid, block, lds, s, a);
+    else if (HP == 96) hipLaunchKernelGGL(gru_mid_fwd_kernel<96>, grid, block, lds, s, a);
+    else hipLaunchKernelGGL(gru_mid_fwd_kernel<128>, grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace tgru

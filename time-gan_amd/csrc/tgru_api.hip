@@ -45,6 +45,14 @@ bool use_vec(int B, int T, int In, int H, int L, int layout) {
     return !(e && e[0] == '1');
 }
 
+// 32 < H <= 128: recurrent kernels with four sequences per workgroup (gru_mid.hip); TGRU_NO_MID=1
+// selects the 16-sequence MFMA kernels of gru_recurrent.hip instead.
+bool use_mid(int H) {
+    if (!gru_mid_supported(H)) return false;
+    const char *e = getenv("TGRU_NO_MID");
+    return !(e && e[0] == '1');
+}
+
 // reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
 size_t reserve_floats(const Dims &d) {
     size_t n = (size_t)d.L * 4 * align64(d.TBH());
@@ -232,10 +240,11 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         g.bmap = id_map(d);
         g.cmap = id_map(d);
         TGRU_HIP(launch_gemm(g, true, true, 1, s));
-        TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
+        const bool mid = use_mid(H);
+        if (!mid) TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
 
         FwdArgs f{};
-        f.gi = gi; f.wp = wp; f.b_hh = b_hh[l];
+        f.gi = gi; f.wp = wp; f.w_hh = w_hh[l]; f.b_hh = b_hh[l];
         f.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         const bool need_int = !top || layout != TGRU_LAYOUT_TBF;
         f.y_int = nullptr;
@@ -247,7 +256,8 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
         f.lengths = lengths;
         f.B = B; f.T = T; f.H = H;
-        TGRU_HIP(launch_gru_fwd(f, s));
+        if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
+        else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;
     }
     return TGRU_OK;

@@ -78,6 +78,7 @@ hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float
 struct FwdArgs {
     const float *gi;        // (T*B, 3H) input projection incl. b_ih, time-major
     const float *wp;        // packed W_hh fragments, see pack_whh_kernel
+    const float *w_hh;      // W_hh as the caller holds it (3H, H): kernels of gru_mid.hip
     const float *b_hh;      // (3H)
     const float *h0;        // (B,H) or null
     float *y_int;           // (T*B, H) time-major layer output
@@ -174,6 +175,10 @@ int small_wgrad_chunks(int B, int T);
 // 16 < H <= 24, In <= 24 specialisation of the whole-stack kernels (gru_h24.hip)
 hipError_t launch_gru_h24_fwd(const SmallFwdArgs &a, hipStream_t s);
 hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s);
+
+// 32 < H <= 128, four sequences per workgroup on 4x4x1 MFMAs (gru_mid.hip)
+bool gru_mid_supported(int H);
+hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s);
 
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
