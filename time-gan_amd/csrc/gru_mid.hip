@@ -197,7 +197,191 @@ __global__ __launch_bounds__(448) void gru_mid_fwd_kernel(FwdArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// backward: dg_t (gradients of the gate pre-activations, written for the weight-gradient and dX
+// GEMMs) and the state-gradient recurrence  dh_{t-1} = keep_t + W_hh^T . dgh_t
+// ----------------------------------------------------------------------------------------------
+template <int HP>
+__global__ __launch_bounds__(448) void gru_mid_bwd_kernel(BwdArgs a) {
+    using namespace mid;
+    // direct-to-LDS loads per step: the four gate planes [4][kSeq][H], then h_{t-1} [kSeq][H], then dy [kSeq][H]
+    constexpr int NIG = (4 * HP + 63) / 64, NIY = (HP + 63) / 64, NI = NIG + 2 * NIY;
+    // ops[kSlots][NI*256] | dgs[kSeq][3][HP] | part[3][kSeq][RS]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.H, B = a.B, T = a.T;
+    const int nhs = (H + 63) / 64;                // 64-row slices of the H output rows
+    const int nwc = 3 * nhs;                      // compute waves (gate, slice); wave nwc is the loader
+    const int RS = nhs * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *ops = smem;
+    float *dgs = ops + kSlots * NI * 256;
+    float *part = dgs + kSeq * 3 * HP;
+    const int b0 = blockIdx.x * kSeq;
+    const long plane = (long)T * B * H;
+
+    if (wave == nwc) {
+        // ---- loader: step k handles time t = T-1-k ----------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gates, 4 * plane * 4);
+        const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y_int, plane * 4);
+        const float *dyp = a.dy_int ? a.dy_int : a.dy_ext;
+        const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyp, plane * 4);
+        const bool dy_bt = !a.dy_int && a.dymap.mode == 1;              // caller's dy is (B,T,H)
+        auto issue = [&](int k) {
+            const int t = T - 1 - k;
+            float *slot = ops + (k % kSlots) * NI * 256;
+#pragma unroll
+            for (int i = 0; i < NIG; ++i) {
+                const int e = (i * 64 + lane) * 4;          // element of the flattened [4 planes][kSeq][H] block
+                const int q = e / (kSeq * H), rem = e - q * kSeq * H;
+                const int j = rem / H, off = rem - j * H;
+                const bool ok = t >= 0 && q < 4 && b0 + j < B;
+                lds_load_b128(rs_g, slot + i * 256, ok ? (int)(q * plane * 4) + ((t * B + b0 + j) * H + off) * 4 : kOOB);
+            }
+#pragma unroll
+            for (int i = 0; i < NIY; ++i) {
+                const int e = (i * 64 + lane) * 4;          // element of a [kSeq][H] block
+                const int j = e / H, off = e - j * H;
+                const bool ok = t >= 0 && j < kSeq && b0 + j < B;
+                lds_load_b128(rs_y, slot + (NIG + i) * 256, (ok && t > 0) ? (((t - 1) * B + b0 + j) * H + off) * 4 : kOOB);
+                const int drow = dy_bt ? (b0 + j) * T + t : t * B + b0 + j;
+                lds_load_b128(rs_dy, slot + (NIG + NIY + i) * 256, ok ? (drow * H + off) * 4 : kOOB);
+            }
+        };
+        for (int k = 0; k < kAhead; ++k) issue(k);
+        wait_vmcnt<(kAhead - 1) * NI>();
+        lds_barrier();
+        for (int k = 0; k < T; ++k) {
+            issue(k + kAhead);
+            lds_barrier();                        // A: end of the elementwise phase
+            wait_vmcnt<(kAhead - 1) * NI>();      // operands of step k+1 have landed
+            lds_barrier();                        // B: end of the MFMA phase
+        }
+        wait_vmcnt<0>();
+        return;
+    }
+
+    // ---- wave (g, s): column u = 64 s + lane of gate block g of W_hh, i.e. W_hh[g*H + i][u] for all i --
+    const int g = wave / nhs, sl = wave - g * nhs;
+    const int ucol = sl * 64 + lane;
+    float w[HP];
+    {
+        const bool ok = ucol < H;
+        const float *src = a.w_hh + (long)g * H * H + ucol;
+#pragma unroll
+        for (int i = 0; i < HP; ++i) w[i] = (ok && i < H) ? src[(long)i * H] : 0.f;
+    }
+    // ---- elementwise phase: (sequence, unit) pairs of this thread ---------------------------------------
+    const int nthreads = nwc * 64;
+    const int tid = threadIdx.x;
+    constexpr int kPairs = 2;                     // 4*H pairs over >= 3*64*ceil(H/64) threads
+    int pj[kPairs], pu[kPairs], plen[kPairs];
+    float keep[kPairs], h0v[kPairs], dbs[kPairs][4];
+    bool pin[kPairs], pok[kPairs];
+#pragma unroll
+    for (int s = 0; s < kPairs; ++s) {
+        const int p = tid + s * nthreads;
+        pin[s] = p < kSeq * H;
+        pj[s] = pin[s] ? p / H : 0;
+        pu[s] = pin[s] ? p % H : 0;
+        pok[s] = pin[s] && b0 + pj[s] < B;
+        plen[s] = pok[s] ? (a.lengths ? a.lengths[b0 + pj[s]] : T) : 0;
+        const long sb = (long)(b0 + pj[s]) * H + pu[s];
+        // the gradient of h_n enters as the initial carry: steps past the length pass it through
+        keep[s] = (pok[s] && a.dh_n) ? a.dh_n[sb] : 0.f;
+        h0v[s] = (pok[s] && a.h0) ? a.h0[sb] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbs[s][q] = 0.f;
+    }
+    // zero the padding of the dgh vectors (entries H..HP-1) once
+    for (int i = tid; i < kSeq * 3 * (HP - H); i += nthreads) {
+        const int v = i / (HP - H), c = i % (HP - H);
+        dgs[v * HP + H + c] = 0.f;
+    }
+    const int jl = lane & 3, bl = lane >> 2;
+    wait_loads();
+    lds_barrier();
+
+    for (int k = 0; k < T; ++k) {
+        const int t = T - 1 - k;
+        const float *slot = ops + (k % kSlots) * NI * 256;
+        // ---- elementwise phase ----------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < kPairs; ++s) {
+            if (pin[s]) {
+                const int j = pj[s], u = pu[s];
+                const int o = j * H + u;
+                const float r = slot[o], z = slot[kSeq * H + o], n = slot[2 * kSeq * H + o], hn = slot[3 * kSeq * H + o];
+                const float hp = t > 0 ? slot[NIG * 256 + o] : h0v[s];
+                const float dy = slot[(NIG + NIY) * 256 + o];
+                float dhc = keep[s];
+                if (k > 0 && t + 1 < plen[s])     // the previous step was active: add W_hh^T . dgh of that step
+                    dhc += part[(0 * kSeq + j) * RS + u] + part[(1 * kSeq + j) * RS + u] + part[(2 * kSeq + j) * RS + u];
+                const bool on = t < plen[s];
+                const float d = on ? dy + dhc : 0.f;
+                const float dn = d * (1.f - z);
+                const float dzz = d * (hp - n);
+                const float an = dn * (1.f - n * n);
+                const float dar = an * hn * r * (1.f - r);
+                const float daz = dzz * z * (1.f - z);
+                const float dgn = an * r;
+                keep[s] = on ? d * z : dhc;
+                dgs[(j * 3 + 0) * HP + u] = dar;
+                dgs[(j * 3 + 1) * HP + u] = daz;
+                dgs[(j * 3 + 2) * HP + u] = dgn;
+                dbs[s][0] += dar; dbs[s][1] += daz; dbs[s][2] += an; dbs[s][3] += dgn;
+                if (pok[s]) {
+                    float *dg = a.dg + ((long)t * B + b0 + j) * 4 * H + u;
+                    dg[0] = dar; dg[H] = daz; dg[2 * H] = an; dg[3 * H] = dgn;
+                }
+            }
+        }
+        lds_barrier();   // A
+        // ---- MFMA phase: part[g][j][u] = sum_i W_hh[g*H + i][u] * dgh_g[j][i] ----------------------------
+        {
+            const float *v = dgs + (jl * 3 + g) * HP;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int q = 0; q < HP / 4; ++q) {
+                const float4 x = *reinterpret_cast<const float4 *>(v + 4 * q);
+                acc0 = mfma4(w[4 * q], x.x, acc0);
+                acc1 = mfma4(w[4 * q + 1], x.y, acc1);
+                acc0 = mfma4(w[4 * q + 2], x.z, acc0);
+                acc1 = mfma4(w[4 * q + 3], x.w, acc1);
+            }
+            mfma_drain();
+            *reinterpret_cast<float4 *>(part + (g * kSeq + jl) * RS + sl * 64 + 4 * bl) =
+                make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+        }
+        lds_barrier();   // B
+    }
+    // ---- dh0 and the per-sequence bias-gradient partial sums --------------------------------------------
+#pragma unroll
+    for (int s = 0; s < kPairs; ++s) {
+        if (!pok[s]) continue;
+        const int j = pj[s], u = pu[s];
+        float dh = keep[s];
+        if (0 < plen[s]) dh += part[(0 * kSeq + j) * RS + u] + part[(1 * kSeq + j) * RS + u] + part[(2 * kSeq + j) * RS + u];
+        if (a.dh0) a.dh0[(long)(b0 + j) * H + u] = dh;
+        float *dbp = a.db_part + (long)(b0 + j) * 4 * H + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbp[q * H] = dbs[s][q];
+    }
+}
+
 bool gru_mid_supported(int H) { return H > 32 && H <= 128 && (H & 3) == 0; }
+
+hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s) {
+    const int nhs = (a.H + 63) / 64, nwc = 3 * nhs;
+    dim3 grid((a.B + mid::kSeq - 1) / mid::kSeq), block(64 * (nwc + 1));
+    const int HP = a.H <= 64 ? 64 : (a.H <= 96 ? 96 : 128);
+    const int NI = (4 * HP + 63) / 64 + 2 * ((HP + 63) / 64);
+    const size_t lds = (size_t)(mid::kSlots * NI * 256 + mid::kSeq * 3 * HP + 3 * mid::kSeq * nhs * 64) * sizeof(float);
+    if (HP == 64) hipLaunchKernelGGL(gru_mid_bwd_kernel<64>, grid, block, lds, s, a);
+    else if (HP == 96) hipLaunchKernelGGL(gru_mid_bwd_kernel<96>, grid, block, lds, s, a);
+    else hipLaunchKernelGGL(gru_mid_bwd_kernel<128>, grid, block, lds, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s) {
     const int nw = (3 * a.H + 63) / 64;

@@ -465,12 +465,33 @@ hipError_t launch_gru_bwd(const BwdArgs &a, hipStream_t s) {
 }
 
 // db_ih = sums of (da_r | da_z | da_n), db_hh = sums of (da_r | da_z | da_n*r)
+// db_ih / db_hh = column sums of the per-workgroup (or per-sequence) partial sums part[nblocks][4H]
+// (columns: da_r | da_z | da_n | da_n*r).  Workgroup = 32 columns x 8 row groups; a group sums a
+// contiguous range of rows with four interleaved accumulators, the groups combine in fixed order.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float *part, int nblocks, int H, float *db_ih,
                                                         float *db_hh, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4 * H) return;
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    const int per = (nblocks + 7) / 8;
+    const int k0 = grp * per, k1 = min(nblocks, k0 + per);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (i < 4 * H) {
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            v0 += part[(long)k * 4 * H + i];
+            v1 += part[(long)(k + 1) * 4 * H + i];
+            v2 += part[(long)(k + 2) * 4 * H + i];
+            v3 += part[(long)(k + 3) * 4 * H + i];
+        }
+        for (; k < k1; ++k) v0 += part[(long)k * 4 * H + i];
+    }
+    red[grp][c] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (grp != 0 || i >= 4 * H) return;
     float v = 0.f;
-    for (int k = 0; k < nblocks; ++k) v += part[(long)k * 4 * H + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += red[q][c];
     if (i < 3 * H) {
         db_ih[i] = accumulate ? db_ih[i] + v : v;
         if (i < 2 * H) db_hh[i] = accumulate ? db_hh[i] + v : v;
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *part, int n
 
 hipError_t launch_bias_grad(const float *db_part, int nblocks, int H, float *db_ih, float *db_hh,
                             int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, db_part, nblocks, H,
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, s, db_part, nblocks, H,
                        db_ih, db_hh, accumulate);
     return hipGetLastError();
 }

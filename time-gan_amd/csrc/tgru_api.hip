@@ -100,6 +100,7 @@ BwdWs bwd_ws(const Dims &d) {
     size_t nblk = (size_t)gru_batch_blocks(d.B);
     const bool vec_shape = gru_vec_supported(d.B, d.T, d.In, d.H, d.L);
     if (vec_shape && (size_t)gru_vec_workgroups(d.B) > nblk) nblk = (size_t)gru_vec_workgroups(d.B);
+    if (gru_mid_supported(d.H)) nblk = (size_t)d.B;      // those kernels leave one bias partial per sequence
     w.dbp = off; off += align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
@@ -335,14 +336,16 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         const bool top = l == L - 1;
         const float *y_l = (top && layout == TGRU_LAYOUT_TBF) ? y : reserve_y(d, res, l);
         const float *in = l == 0 ? x : reserve_y(d, res, l - 1);
-        TGRU_HIP(launch_pack_whh(w_hh[l], nullptr, wtp, H, s));
+        // the four-sequence kernels read the caller's dy directly only in the padded layouts
+        const bool mid = use_mid(H) && !(top && layout == TGRU_LAYOUT_PACKED);
+        if (!mid) TGRU_HIP(launch_pack_whh(w_hh[l], nullptr, wtp, H, s));
 
         BwdArgs b{};
         b.dy_int = top ? nullptr : workspace + w.dyb + (size_t)((l + 1) & 1) * dyb_stride;
         b.dy_ext = top ? dy : nullptr;
         b.dymap = ext_map(d, toff);
         b.dh_n = dh_n ? dh_n + (size_t)l * B * H : nullptr;
-        b.wtp = wtp; b.y_int = y_l;
+        b.wtp = wtp; b.w_hh = w_hh[l]; b.y_int = y_l;
         b.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         b.gates = reserve_gates(d, res, l);
         b.dg = dg;
@@ -350,8 +353,9 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         b.db_part = dbp;
         b.lengths = lengths;
         b.B = B; b.T = T; b.H = H;
-        TGRU_HIP(launch_gru_bwd(b, s));
-        TGRU_HIP(launch_bias_grad(dbp, nblk, H, db_ih[l], db_hh[l], accumulate, s));
+        if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
+        else TGRU_HIP(launch_gru_bwd(b, s));
+        TGRU_HIP(launch_bias_grad(dbp, mid ? B : nblk, H, db_ih[l], db_hh[l], accumulate, s));
 
         // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
         {

@@ -97,6 +97,7 @@ struct BwdArgs {
     RowMap dymap;
     const float *dh_n;      // (B,H) or null
     const float *wtp;       // packed W_hh^T fragments, see pack_whh_t_kernel
+    const float *w_hh;      // W_hh as the caller holds it (3H, H): kernels of gru_mid.hip
     const float *y_int;     // (T*B, H) this layer's output (h_t), time-major
     const float *h0;        // (B,H) or null
     const float *gates;     // 4 planes (r,z,n,hn)
@@ -179,6 +180,7 @@ hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s);
 // 32 < H <= 128, four sequences per workgroup on 4x4x1 MFMAs (gru_mid.hip)
 bool gru_mid_supported(int H);
 hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s);
+hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s);   // db_part: one row of 4H per SEQUENCE
 
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
