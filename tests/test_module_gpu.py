@@ -105,6 +105,36 @@ def test_no_grad_and_time_major_and_hx():
         assert_close(po_.grad.cpu().numpy(), pr_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, name)
 
 
+def test_mid_hidden_with_initial_state_and_ragged_lengths():
+    """H = 64 / 96 take the four-sequences-per-workgroup kernels and (B multiple of 16) the one-pass
+    weight-gradient kernel, whose first rows pair with the initial state."""
+    import timegan_amd as tg
+    for (B, T, In, H, L, lens) in ((32, 6, 48, 64, 2, [6] * 10 + [4] * 12 + [1] * 10), (16, 5, 96, 96, 1, None)):
+        torch.manual_seed(B + H)
+        ref = nn.GRU(In, H, L, batch_first=True)
+        ours = tg.GRU(In, H, L, batch_first=True).to("cuda:0")
+        ours.load_state_dict(ref.state_dict())
+        x = torch.rand(B, T, In)
+        h0 = torch.randn(L, B, H)
+        xr = x.clone().requires_grad_(True); hr0 = h0.clone().requires_grad_(True)
+        xo = x.clone().cuda().requires_grad_(True); ho0 = h0.clone().cuda().requires_grad_(True)
+        lens_ = [T] * B if lens is None else lens
+        pr = nn.utils.rnn.pack_padded_sequence(xr, lens_, batch_first=True, enforce_sorted=True)
+        yr, hnr = ref(pr, hr0)
+        yr, _ = nn.utils.rnn.pad_packed_sequence(yr, batch_first=True, padding_value=0, total_length=T)
+        yo, hno = ours(xo, ho0, lengths=lens)
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1))
+        ((yr * gy).sum() + hnr.sum()).backward()
+        ((yo * gy.cuda()).sum() + hno.sum()).backward()
+        tag = f"H{H}"
+        assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " y")
+        assert_close(hno.detach().cpu().numpy(), hnr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " h_n")
+        assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dx")
+        assert_close(ho0.grad.cpu().numpy(), hr0.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dh0")
+        for (name, p_), (_, q_) in zip(ref.named_parameters(), ours.named_parameters()):
+            assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
+
+
 def test_reference_smoke_shapes_lengths_of_one_and_deep_stack():
     """run_embedding_test (TimeGANv1.py:77-94): x (10,150,5), t = ones(10) as a FLOAT tensor,
     H = 100, 50 layers -> (10,150,100); rows past length 1 are emb_linear(norm(0))."""

@@ -118,6 +118,11 @@ BwdWs bwd_ws(const Dims &d) {
         const size_t need = (size_t)gru_vec_workgroups(d.B) * small_wgrad_slab_floats(d.In, d.H, d.L);
         if (need > slab_floats) slab_floats = need;
     }
+    if (gru_mid_supported(d.H)) {
+        const int widest_in = d.In > d.H ? d.In : d.H;
+        const size_t need = (size_t)gru_mid_wgrad_workgroups(d.B, d.T) * gru_mid_wgrad_slab_floats(widest_in, d.H);
+        if (need > slab_floats) slab_floats = need;
+    }
     w.slabs = off; off += align64(slab_floats);
     w.total = off;
     return w;
@@ -357,8 +362,15 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         else TGRU_HIP(launch_gru_bwd(b, s));
         TGRU_HIP(launch_bias_grad(dbp, mid ? B : nblk, H, db_ih[l], db_hh[l], accumulate, s));
 
+        const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&
+                               !(l == 0 && layout == TGRU_LAYOUT_PACKED);
+        if (mid_wgrad) {
+            TGRU_HIP(launch_gru_mid_wgrad(dg, in, In_l, l == 0 && layout == TGRU_LAYOUT_BTF, y_l,
+                                          h0 ? h0 + (size_t)l * B * H : nullptr, slabs, dw_ih[l], dw_hh[l], B, T,
+                                          H, accumulate, s));
+        }
         // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
-        {
+        if (!mid_wgrad) {
             int kc;
             const int ns = split_for(3 * H, In_l, TB, &kc);
             GemmArgs g{};
@@ -371,7 +383,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             TGRU_HIP(launch_slab_reduce(slabs, g.slab_stride, ns, dw_ih[l], (long)3 * H * In_l, accumulate, s));
         }
         // dW_hh = dgh^T . h_prev : dg rows of step t pair with this layer's output rows of step t-1
-        {
+        if (!mid_wgrad) {
             int kc;
             const int K = TB - B;
             const int ns = split_for(3 * H, H, K > 0 ? K : 1, &kc);

@@ -182,6 +182,14 @@ bool gru_mid_supported(int H);
 hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s);
 hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s);   // db_part: one row of 4H per SEQUENCE
 
+// both weight gradients of a mid-H layer in one pass over the rows (gru_mid_wgrad.hip)
+bool gru_mid_wgrad_supported(int B, int T, int In, int H);
+int gru_mid_wgrad_workgroups(int B, int T);
+long gru_mid_wgrad_slab_floats(int In, int H);
+hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
+                                const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
+                                int accumulate, hipStream_t s);
+
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
 hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s);
