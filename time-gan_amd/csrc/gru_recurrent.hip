@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
     const int H = a.H, B = a.B, T = a.T;
     const int nHT = hidden_tiles(H);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile offsets stay in SGPRs
     const int b = lane & 15, gq = lane >> 4;
     const int bglob = blockIdx.x * 16 + b;
     const bool bvalid = bglob < B;
@@ -101,7 +101,10 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
     const float *wsrc = WLDS ? lds_w : a.wp;
 
     // per-lane state: hidden values of the owned tiles, recurrent biases
-    float hreg[TPW][4], bh[TPW][3][4];
+    float hreg[TPW][4];
+    // recurrent biases: registers when one or two tiles per wave, re-read (cache hits) per step otherwise
+    constexpr bool kBiasRegs = TPW <= 2;
+    float bh[kBiasRegs ? TPW : 1][3][4];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int tile = wave * TPW + i;
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
             const bool ok = tile < nHT && j < H;
             hreg[i][c] = (ok && bvalid && a.h0) ? a.h0[(long)bglob * H + j] : 0.f;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) bh[i][g][c] = ok ? a.b_hh[g * H + j] : 0.f;
+            for (int g = 0; g < 3; ++g)
+                if (kBiasRegs) bh[kBiasRegs ? i : 0][g][c] = ok ? a.b_hh[g * H + j] : 0.f;
         }
         if (tile < nHT)
             *reinterpret_cast<float4 *>(lds_h + (tile * 64 + lane) * 4) =
@@ -123,7 +127,60 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
     for (int t = 0; t < T; ++t) {
         const bool active = t < len;
         const long row = (long)t * B + bglob;
-        // input projection of this step for the owned hidden units (issued early)
+        f32x4 acc[TPW][3];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        const float *hcur = lds_h + cur * nHT * 256;
+        // one k-block: the three gate fragments of every owned tile times the h fragment
+        auto load_w = [&](int q, float4 (&wf)[TPW][3]) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = min(wave * TPW + i, nHT - 1);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    wf[i][g] = *reinterpret_cast<const float4 *>(
+                        wsrc + ((((long)g * nHT + tile) * nHT + q) * 64 + lane) * 4);
+            }
+        };
+        auto block = [&](int q, const float4 (&wf)[TPW][3]) {
+            const float4 hf = *reinterpret_cast<const float4 *>(hcur + (q * 64 + lane) * 4);
+            const float hv[4] = {hf.x, hf.y, hf.z, hf.w};
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (wave * TPW + i < nHT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const float wv = c == 0 ? wf[i][g].x : c == 1 ? wf[i][g].y : c == 2 ? wf[i][g].z : wf[i][g].w;
+                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, hv[c], acc[i][g], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        if (WLDS) {
+            for (int q = 0; q < nHT; ++q) {
+                float4 wf[TPW][3];
+                load_w(q, wf);
+                block(q, wf);
+            }
+        } else {
+            // weights streamed from L2: the fragments of k-block q+1 are in flight while q multiplies
+            float4 w0[TPW][3], w1[TPW][3];
+            load_w(0, w0);
+            for (int q = 0; q < nHT; q += 2) {
+                if (q + 1 < nHT) load_w(q + 1, w1);
+                block(q, w0);
+                if (q + 2 < nHT) load_w(q + 2, w0);
+                if (q + 1 < nHT) block(q + 1, w1);
+            }
+        }
+
+        // input projection of this step for the owned hidden units (after the k loop: held across it, these 12 registers per tile spill the streamed-weight variant)
         float gi[TPW][3][4];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -143,37 +200,6 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
             }
         }
 
-        f32x4 acc[TPW][3];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        const float *hcur = lds_h + cur * nHT * 256;
-        for (int q = 0; q < nHT; ++q) {
-            const float4 hf = *reinterpret_cast<const float4 *>(hcur + (q * 64 + lane) * 4);
-            const float hv[4] = {hf.x, hf.y, hf.z, hf.w};
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int tile = wave * TPW + i;
-                if (tile < nHT) {
-                    float4 wf[3];
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        wf[g] = *reinterpret_cast<const float4 *>(
-                            wsrc + ((((long)g * nHT + tile) * nHT + q) * 64 + lane) * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            const float wv = c == 0 ? wf[g].x : c == 1 ? wf[g].y : c == 2 ? wf[g].z : wf[g].w;
-                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, hv[c], acc[i][g], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-
         mfma_drain();
         float *hnxt = lds_h + (cur ^ 1) * nHT * 256;
 #pragma unroll
@@ -184,9 +210,13 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(FwdArgs a) {
             float yv[4], rv[4], zv[4], nv[4], hnv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float ghn = acc[i][2][c] + bh[i][2][c];
-                const float r = fast_sigmoid(gi[i][0][c] + acc[i][0][c] + bh[i][0][c]);
-                const float z = fast_sigmoid(gi[i][1][c] + acc[i][1][c] + bh[i][1][c]);
+                const bool jok = j0 + c < H;
+                const float b_r = kBiasRegs ? bh[kBiasRegs ? i : 0][0][c] : (jok ? a.b_hh[j0 + c] : 0.f);
+                const float b_z = kBiasRegs ? bh[kBiasRegs ? i : 0][1][c] : (jok ? a.b_hh[H + j0 + c] : 0.f);
+                const float b_n = kBiasRegs ? bh[kBiasRegs ? i : 0][2][c] : (jok ? a.b_hh[2 * H + j0 + c] : 0.f);
+                const float ghn = acc[i][2][c] + b_n;
+                const float r = fast_sigmoid(gi[i][0][c] + acc[i][0][c] + b_r);
+                const float z = fast_sigmoid(gi[i][1][c] + acc[i][1][c] + b_z);
                 const float n = fast_tanh(gi[i][2][c] + r * ghn);
                 const float hnew = (1.f - z) * n + z * hreg[i][c];
                 rv[c] = r; zv[c] = z; nv[c] = n; hnv[c] = ghn;
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(BwdArgs a) {
     const int H = a.H, B = a.B, T = a.T;
     const int nHT = hidden_tiles(H);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile offsets stay in SGPRs
     const int b = lane & 15, gq = lane >> 4;
     const int bglob = blockIdx.x * 16 + b;
     const bool bvalid = bglob < B;
@@ -414,18 +444,46 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(BwdArgs a) {
         f32x4 acc[TPW][2];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-        for (int qq = 0; qq < 3 * nHT; ++qq) {
+        const int nq = 3 * nHT;
+        auto load_wt = [&](int qq, float4 (&wf)[TPW]) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = min(wave * TPW + i, nHT - 1);
+                wf[i] = *reinterpret_cast<const float4 *>(wsrc + (((long)tile * 3 * nHT + qq) * 64 + lane) * 4);
+            }
+        };
+        auto block_t = [&](int qq, const float4 (&wf)[TPW]) {
             const float4 gf = *reinterpret_cast<const float4 *>(lds_g + (qq * 64 + lane) * 4);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int tile = wave * TPW + i;
-                if (tile < nHT) {
-                    const float4 wf = *reinterpret_cast<const float4 *>(
-                        wsrc + (((long)tile * 3 * nHT + qq) * 64 + lane) * 4);
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, gf.x, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, gf.y, acc[i][1], 0, 0, 0);
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, gf.z, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, gf.w, acc[i][1], 0, 0, 0);
+                if (wave * TPW + i < nHT) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, gf.x, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, gf.y, acc[i][1], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].z, gf.z, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].w, gf.w, acc[i][1], 0, 0, 0);
+                }
+            }
+        };
+        if (WLDS) {
+            for (int qq = 0; qq < nq; ++qq) {
+                float4 wf[TPW];
+                load_wt(qq, wf);
+                block_t(qq, wf);
+            }
+        } else {
+            // weights streamed from L2: the fragments of the next kDepth k-blocks are in flight
+            constexpr int kDepth = 4;
+            float4 ring[kDepth][TPW];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) load_wt(min(d, nq - 1), ring[d]);
+            for (int q0 = 0; q0 < nq; q0 += kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int qq = q0 + d;
+                    if (qq < nq) {
+                        block_t(qq, ring[d]);
+                        load_wt(min(qq + kDepth, nq - 1), ring[d]);
+                    }
                 }
             }
         }
