@@ -107,8 +107,10 @@ def joint_training_probe(tg, dev, features, H, L, T, B, group, iters=3):
     for prefix, graphs in modes:
         torch.manual_seed(42)
         tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs)
-        for name, fn, n in (("embedding", tr.embedding_step, 20), ("supervisor", tr.supervisor_step, 20),
-                            ("joint", tr.joint_step, iters * (4 if graphs else 1))):
+        short = group is not None      # data-parallel probe: fewer iterations, it is launch-bound anyway
+        for name, fn, n in (("embedding", tr.embedding_step, 10 if short else 20),
+                            ("supervisor", tr.supervisor_step, 10 if short else 20),
+                            ("joint", tr.joint_step, 2 if short else iters * (4 if graphs else 1))):
             for _ in range(3):
                 fn(x)
             torch.cuda.synchronize()
@@ -120,6 +122,15 @@ def joint_training_probe(tg, dev, features, H, L, T, B, group, iters=3):
     out["note"] = ("PyTorch autograd around the HIP GRU, batch %d per GPU, %d features; the eager figures "
                    "are host-launch bound at this size" % (B, features))
     return out
+
+
+def device_barrier(dist, dev):
+    """Barrier as an all-reduce of a device tensor: ordered with every other collective of this bench
+    on the same device queue (a host-side barrier is not, with backends that run device-tensor
+    collectives asynchronously), then drained."""
+    t = torch.zeros(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
 
 
 def main():
@@ -136,6 +147,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("TGRU_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["TGRU_BENCH_WATCHDOG"]), exit=True,
+                                          file=open(f"gpurun_out/bench_watchdog_rank{rank}.log", "w"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
@@ -170,7 +185,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        device_barrier(dist, dev)
     torch.cuda.synchronize()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -184,7 +199,7 @@ def main():
             dist.all_reduce(runner.flat_grads)
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        device_barrier(dist, dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
@@ -235,7 +250,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
         print(json.dumps(out), flush=True)
     if dist:
-        dist.barrier()
+        device_barrier(dist, dev)
         dist.destroy_process_group()
 
 
