@@ -188,11 +188,13 @@ def main():
         device_barrier(dist, dev)
     torch.cuda.synchronize()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    evm = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev0[i].record()
         runner.forward(x)
+        evm[i].record()
         runner.backward(dy)
         ev1[i].record()
         if do_ar:
@@ -208,6 +210,8 @@ def main():
         elapsed = float(tmax.item())
     dev_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    fwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(ev0, evm)) / len(ev0)
+    bwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(evm, ev1)) / len(ev0)
 
     joint = None
     if not args.no_joint and args.workload == "c2":
@@ -232,6 +236,16 @@ def main():
         roof["kernel"] = "whole step: every kernel of one stack forward+backward (HIP events around the step)"
         roof["device_ms_per_step"] = round(dev_ms_avg, 4)
         roof["device_ms_median"] = round(dev_ms[len(dev_ms) // 2], 4)
+        # the two halves of the step priced separately (forward kernel(s); backward + gradient reduce)
+        wbytes = sum(4.0 * (3 * H * (In if l == 0 else H) + 3 * H * H + 6 * H) for l in range(L))
+        fb = B * T * 4.0 * sum(6 * H for _ in range(L)) + wbytes            # x/y + 4 saved gate values
+        bb = bytes_ - fb
+        ff, bf = flops / 3.0, flops * 2.0 / 3.0
+        roof["parts"] = {
+            "forward": {"device_ms": round(fwd_ms_avg, 4), "GB/s": round(fb / fwd_ms_avg / 1e6, 2),
+                        "TFLOP/s": round(ff / fwd_ms_avg / 1e9, 3)},
+            "backward": {"device_ms": round(bwd_ms_avg, 4), "GB/s": round(bb / bwd_ms_avg / 1e6, 2),
+                         "TFLOP/s": round(bf / bwd_ms_avg / 1e9, 3)}}
         roof["algorithmic_bytes_per_step"] = bytes_
         roof["algorithmic_flops_per_step"] = flops
         out = {

@@ -20,7 +20,7 @@ __host__ __device__ inline int wg_ldg(int H) { return ((4 * H + 31) / 32) * 32 +
 
 __global__ __launch_bounds__(512) void gru_wgrad_partial_kernel(SmallWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = a.H, B = a.B, L = a.L;
+    const int H = a.H, B = a.B;
     const int l = blockIdx.y, chunk = blockIdx.x;
     const int In_l = (l == 0) ? a.In : H;
     const int K = a.T * B;
