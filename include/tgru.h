@@ -161,6 +161,39 @@ int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int di
                        float eps, float *dparams, float *workspace, int accumulate,
                        tgru_stream_t stream);
 
+/*
+ * The loss expressions of the three training phases, fused (no reference FFI; they replace the
+ * torch compositions at outdated_files/TimeGANv1.py:410-553):
+ *   TGRU_LOSS_EMBED_SIDE     in = {x_tilde, x}                    out[0] = 10 sqrt(mse)            (:420-421)
+ *   TGRU_LOSS_SUPERVISOR     in = {h_sup, h}                      out[0] = mse(h_sup[:, :-1], h[:, 1:])  (:470)
+ *   TGRU_LOSS_EMBED_MAIN     in = {x_tilde, x, h_sup, h}          out = e_loss, e_loss0, e_loss_t0 (:444-451)
+ *   TGRU_LOSS_DISCRIMINATOR  in = {y_real, y_fake, y_fake_e}      out[0] = d_loss                  (:497-503)
+ *   TGRU_LOSS_GENERATOR      in = {y_fake, y_fake_e, h_sup, h, x_hat, x}   out[0] = g_loss         (:533-553)
+ * x* are (B, T, F), h* are (B, T, H), y* are (B, T, 1), all dense fp32.  `in` / `din` / `dout` are HOST
+ * arrays of device pointers (6 / 6 / 3 entries; unused entries and unwanted gradients NULL).
+ *
+ * Forward = tgru_loss_partial(pass 0) then tgru_loss_final, through one buffer `buf` of
+ * layout[3] floats (tgru_loss_layout); the outputs are the 3 floats at buf[layout[2]], and `buf` is
+ * what tgru_loss_backward needs.  Data-parallel ranks holding shards of one batch instead run
+ * partial(pass 1), sum buf[0 .. layout[0]) over ranks, then (generator only) partial(pass 2) and
+ * sum buf[layout[0] .. layout[0]+layout[1]) over ranks, then final: every rank then holds the loss
+ * of the whole batch and tgru_loss_backward gives its gradient w.r.t. the local rows.
+ * tgru_loss_backward writes din[i] = sum_j dout[j][0] * d out[j] / d in[i] for every non-NULL din[i].
+ */
+enum {
+    TGRU_LOSS_EMBED_SIDE = 0,
+    TGRU_LOSS_SUPERVISOR = 1,
+    TGRU_LOSS_EMBED_MAIN = 2,
+    TGRU_LOSS_DISCRIMINATOR = 3,
+    TGRU_LOSS_GENERATOR = 4
+};
+int tgru_loss_layout(int kind, int T, int F, int64_t layout[4]);
+int tgru_loss_partial(int kind, int pass, const float *const *in, int B, int T, int H, int F, float *buf,
+                      tgru_stream_t stream);
+int tgru_loss_final(int kind, int B, int T, int H, int F, float gamma, float *buf, tgru_stream_t stream);
+int tgru_loss_backward(int kind, const float *const *in, float *const *din, const float *const *dout,
+                       int B, int T, int H, int F, float gamma, const float *buf, tgru_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

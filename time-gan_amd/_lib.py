@@ -31,6 +31,10 @@ SIGNATURES = {
     "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),
     "tgru_head_forward": (_i, [_vp] * 2 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp]),
     "tgru_head_backward": (_i, [_vp] * 3 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp, _vp, _i, _vp]),
+    "tgru_loss_layout": (_i, [_i] * 3 + [ctypes.POINTER(ctypes.c_int64)]),
+    "tgru_loss_partial": (_i, [_i, _i, _vp] + [_i] * 4 + [_vp, _vp]),
+    "tgru_loss_final": (_i, [_i] * 5 + [ctypes.c_float, _vp, _vp]),
+    "tgru_loss_backward": (_i, [_i, _vp, _vp, _vp] + [_i] * 4 + [ctypes.c_float, _vp, _vp]),
 }
 
 

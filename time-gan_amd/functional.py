@@ -88,6 +88,7 @@ class _GRUFunction(torch.autograd.Function):
             check(rc, "tgru_forward")
         ctx.dims = (B, T, In, H, L, layout)
         ctx.has_h0 = h0 is not None
+        ctx.set_materialize_grads(False)   # an unused h_n (or y) arrives in backward as None, not as zeros
         ctx.save_for_backward(x, h0c, y, lengths, toff, reserve, *weights)
         return y, h_n
 
@@ -97,7 +98,7 @@ class _GRUFunction(torch.autograd.Function):
         x, h0, y, lengths, toff, reserve, *weights = ctx.saved_tensors
         w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
         dev = x.device
-        dy = None if dy is None else dy.contiguous()
+        dy = torch.zeros_like(y) if dy is None else dy.contiguous()   # only h_n was used
         dh_n = None if dh_n is None else dh_n.contiguous()
         with torch.cuda.device(dev):
             lb = lib()

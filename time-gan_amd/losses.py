@@ -13,7 +13,21 @@ from typing import Tuple
 import torch
 import torch.nn.functional as F
 
+from . import loss_ops
 from .parallel import dist_sum, world_size
+
+
+def _fused(kind, tensors, x_like, h_like, gamma=1.0, group=None):
+    """The fused GPU op for loss `kind` (loss_ops) on (B,T,F)-shaped `x_like` / (B,T,H)-shaped `h_like`
+    operands, or None when the tensors are not fp32 GPU tensors (the CPU path of the tests and of the
+    CPU baseline keeps the literal torch composition below)."""
+    if not loss_ops.usable(*tensors):
+        return None
+    ref = h_like if h_like is not None else x_like
+    B, T = ref.shape[0], ref.shape[1]
+    H = h_like.shape[2] if h_like is not None else x_like.shape[2]
+    F = x_like.shape[2] if x_like is not None else h_like.shape[2]
+    return loss_ops.fused_loss(kind, tensors, B, T, H, F, gamma, group)
 
 
 def _count(t: torch.Tensor, group) -> torch.Tensor:
@@ -89,6 +103,9 @@ def embedding_forward_side(emb, rec, x, t, group=None):
     """TimeGANv1.py:410-423 -> (e_loss0, x_tilde)."""
     h = emb(x, t)
     x_tilde = rec(h, t)
+    out = _fused(loss_ops.EMBED_SIDE, [x_tilde, x], x, None, group=group)
+    if out is not None:
+        return out[0], x_tilde
     e_loss_t0 = _mse(x_tilde, x, group)
     return 10 * torch.sqrt(e_loss_t0), x_tilde
 
@@ -97,6 +114,9 @@ def embedding_forward_main(emb, sup, rec, x, t, group=None, streams=None):
     """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0)."""
     h = emb(x, t)
     x_tilde, h_sup = _fork_join([lambda: rec(h, t), lambda: sup(h, t)], streams)
+    out = _fused(loss_ops.EMBED_MAIN, [x_tilde, x, h_sup, h], x, h, group=group)
+    if out is not None:
+        return out
     g_loss_sup = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
     e_loss_t0 = _mse(x_tilde, x, group)
     e_loss0 = 10 * torch.sqrt(e_loss_t0)
@@ -107,6 +127,9 @@ def supervisor_forward(emb, sup, x, t, group=None):
     """TimeGANv1.py:454-472 -> (s_loss, h, h_sup)."""
     h = emb(x, t)
     h_sup = sup(h, t)
+    out = _fused(loss_ops.SUPERVISOR, [h_sup, h], None, h, group=group)
+    if out is not None:
+        return out[0], h, h_sup
     return _mse(h_sup[:, :-1, :], h[:, 1:, :], group), h, h_sup
 
 
@@ -118,6 +141,9 @@ def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None, stream
             return h_, sup(h_, t)
         (h, h_hat), e_hat = _fork_join([real_branch, lambda: g(z, t)], streams)
     y_real, y_fake, y_fake_e = _apply_batched(d, [h, h_hat, e_hat], t)
+    out = _fused(loss_ops.DISCRIMINATOR, [y_real, y_fake, y_fake_e], None, h, gamma, group)
+    if out is not None:
+        return out[0]
     d_loss_real = _bce_logits(y_real, True, group)
     d_loss_fake = _bce_logits(y_fake, False, group)
     d_loss_fake_e = _bce_logits(y_fake_e, False, group)
@@ -134,6 +160,9 @@ def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None, strea
     h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
     x_hat, (y_fake, y_fake_e) = _fork_join([lambda: rec(h_hat, t),
                                             lambda: _apply_batched(d, [h_hat, e_hat], t)], streams)
+    out = _fused(loss_ops.GENERATOR, [y_fake, y_fake_e, h_sup, h, x_hat, x], x, h, gamma, group)
+    if out is not None:
+        return out[0]
     g_loss_u = _bce_logits(y_fake, True, group)
     g_loss_u_e = _bce_logits(y_fake_e, True, group)
     g_loss_s = _mse(h_sup[:, :-1, :], h[:, 1:, :], group)
