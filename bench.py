@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -95,33 +96,33 @@ def cpu_baseline(B, T, In, H, L, budget_s=20.0):
                        + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}" for r in results))}
 
 
-def joint_training_probe(tg, dev, features, H, L, T, B, group, iters=3):
+def joint_training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3):
     """Secondary figure: 3-phase TimeGAN steps on the HIP GRU (TimeGANv1.py:573-812 loop bodies).
     One joint iteration = 10 x (generator step + embedder step) + 1 discriminator step
-    = 116 GRU-stack forwards + 103 backwards plus the MLP / LayerNorm / Adam work around them.
-    Measured eagerly and, on one GPU, with each optimiser sub-step replayed as a HIP graph."""
+    = 116 GRU-stack forwards + 103 backwards plus the heads / losses / Adam work around them.
+    Measured eagerly and (`graphs`) with each optimiser sub-step replayed as a HIP graph; with a
+    process group the graphs contain the RCCL all-reduces.  Fills `out` key by key, so what has been
+    measured survives if a later part does not finish."""
     cfg = tg.make_cfg(features=features, hidden=H, layers=L, seq_len=T, device=str(dev))
     x = torch.rand(B, T, features, device=dev)
-    out = {}
-    modes = [("", False)] + ([("hipgraph_", True)] if group is None else [])
-    for prefix, graphs in modes:
-        torch.manual_seed(42)
-        tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs)
-        short = group is not None      # data-parallel probe: fewer iterations, it is launch-bound anyway
-        for name, fn, n in (("embedding", tr.embedding_step, 10 if short else 20),
-                            ("supervisor", tr.supervisor_step, 10 if short else 20),
-                            ("joint", tr.joint_step, 2 if short else iters * (4 if graphs else 1))):
-            for _ in range(3):
-                fn(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn(x)
-            torch.cuda.synchronize()
-            out[f"{prefix}{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
-    out["note"] = ("PyTorch autograd around the HIP GRU, batch %d per GPU, %d features; the eager figures "
-                   "are host-launch bound at this size" % (B, features))
-    return out
+    prefix = "hipgraph_" if graphs else ""
+    torch.manual_seed(42)
+    tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs)
+    if graphs and not tr.use_graphs:
+        out["hipgraph_note"] = "graph mode not available with this backend"
+        return
+    short = group is not None and not graphs      # eager data-parallel probe: launch-bound, keep it short
+    for name, fn, n in (("embedding", tr.embedding_step, 10 if short else 20),
+                        ("supervisor", tr.supervisor_step, 10 if short else 20),
+                        ("joint", tr.joint_step, 2 if short else iters * (4 if graphs else 1))):
+        for _ in range(3):
+            fn(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn(x)
+        torch.cuda.synchronize()
+        out[f"{prefix}{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
 
 
 def device_barrier(dist, dev):
@@ -143,6 +144,9 @@ def main():
     ap.add_argument("--no-allreduce", action="store_true")
     ap.add_argument("--no-joint", action="store_true", help="skip the secondary 3-phase training probe")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-rank code path (process group, all-reduces, graph capture of "
+                         "them) with a single rank; set TIMEGAN_FORCE_COLLECTIVES=1 as well")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,15 +157,17 @@ def main():
                                           file=open(f"gpurun_out/bench_watchdog_rank{rank}.log", "w"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # one GPU per rank; the modulo only matters when ranks are rehearsed on fewer GPUs (gloo backend)
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    if multi:
         kw = {"device_id": dev} if args.backend == "nccl" else {}
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     import timegan_amd as tg
@@ -173,7 +179,7 @@ def main():
     dy = torch.randn(T, B, H, device=dev)
     runner = tg.GRURunner(B, T, In, H, L, tg.LAYOUT_TBF, dev)
     runner.set_weights(weights)
-    do_ar = world > 1 and not args.no_allreduce
+    do_ar = multi and not args.no_allreduce
 
     def step():
         runner.forward(x)
@@ -213,10 +219,7 @@ def main():
     fwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(ev0, evm)) / len(ev0)
     bwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(evm, ev1)) / len(ev0)
 
-    joint = None
-    if not args.no_joint and args.workload == "c2":
-        joint = joint_training_probe(tg, dev, 6, H, L, T, B, None if world == 1 else dist.group.WORLD)
-
+    out = None
     if rank == 0:
         flops, bytes_ = algorithmic_work(B, T, In, H, L)
         value = world * B * args.steps / elapsed
@@ -258,11 +261,45 @@ def main():
                        "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
             "roofline": roof,
         }
-        if joint is not None:
+
+    printed = []
+
+    def emit():
+        """Rank 0 prints the one result line, once."""
+        if rank == 0 and not printed:
+            printed.append(True)
+            print(json.dumps(out), flush=True)
+
+    if not args.no_joint and args.workload == "c2":
+        joint = {"note": "PyTorch autograd around the HIP GRU / head / loss kernels, batch %d per GPU, 6 features; "
+                         "the eager figures are host-launch bound at this size" % B}
+        if rank == 0:
             out["timegan_training"] = joint
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
-        print(json.dumps(out), flush=True)
+        group = dist.group.WORLD if multi else None
+        joint_training_probe(tg, dev, 6, H, L, T, B, group, False, joint)
+        if multi:
+            # Graph replay with the RCCL all-reduces captured inside.  If a rank fails or stalls here
+            # the process group cannot be trusted any more: report what has been measured and leave.
+            def bail():
+                joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish; eager figures only"
+                emit()
+                os._exit(0)
+            guard = threading.Timer(120.0, bail)
+            guard.daemon = True
+            guard.start()
+            try:
+                joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
+            except Exception as e:      # noqa: BLE001
+                joint["hipgraph_note"] = "graph-mode data-parallel probe failed: " + str(e)[:200]
+                emit()
+                os._exit(0)
+            device_barrier(dist, dev)
+            guard.cancel()
+        else:
+            joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
+    emit()
     if dist:
         device_barrier(dist, dev)
         dist.destroy_process_group()

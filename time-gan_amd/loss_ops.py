@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import check, lib
-from .parallel import world_size
+from .parallel import multi_rank
 
 EMBED_SIDE, SUPERVISOR, EMBED_MAIN, DISCRIMINATOR, GENERATOR = range(5)
 
@@ -56,7 +56,7 @@ class _LossFunction(torch.autograd.Function):
             inp = _ptrs(tensors, 6)
             st = _stream(dev)
             bp = ctypes.c_void_p(buf.data_ptr())
-            if world_size(group) == 1:
+            if not multi_rank(group):
                 check(lb.tgru_loss_partial(kind, 0, inp, B, T, H, F, bp, st), "tgru_loss_partial")
             else:
                 check(lb.tgru_loss_partial(kind, 1, inp, B, T, H, F, bp, st), "tgru_loss_partial")

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import loss_ops
-from .parallel import dist_sum, world_size
+from .parallel import dist_sum, multi_rank
 
 
 def _fused(kind, tensors, x_like, h_like, gamma=1.0, group=None):
@@ -32,18 +32,18 @@ def _fused(kind, tensors, x_like, h_like, gamma=1.0, group=None):
 
 def _count(t: torch.Tensor, group) -> torch.Tensor:
     n = torch.tensor(float(t.numel()), device=t.device)
-    return dist_sum(n, group) if world_size(group) > 1 else n
+    return dist_sum(n, group) if multi_rank(group) else n
 
 
 def _mse(a: torch.Tensor, b: torch.Tensor, group=None) -> torch.Tensor:
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return F.mse_loss(a, b)
     return dist_sum(((a - b) ** 2).sum(), group) / _count(a, group)
 
 
 def _bce_logits(y: torch.Tensor, target_one: bool, group=None) -> torch.Tensor:
     target = torch.ones_like(y) if target_one else torch.zeros_like(y)
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return F.binary_cross_entropy_with_logits(y, target)
     s = F.binary_cross_entropy_with_logits(y, target, reduction="sum")
     return dist_sum(s, group) / _count(y, group)
@@ -51,7 +51,7 @@ def _bce_logits(y: torch.Tensor, target_one: bool, group=None) -> torch.Tensor:
 
 def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """mean(dim=0) and std(dim=0, unbiased=False) over the GLOBAL batch."""
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return v.mean(dim=0), v.std(dim=0, unbiased=False)
     # Everything computed after a dist_sum must be the same on every rank (its backward is the
     # identity), so the variance comes from all-reduced raw moments, taken about a constant close to

@@ -6,14 +6,26 @@ evaluates the SAME global loss value, built from global statistics that are obta
 gradient that flows through its own shard, so parameter gradients are combined with an all-reduce
 SUM (never an average) over one flat bucket per optimiser group.
 """
+import os
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+# Testing aid: run every collective even in a group of one rank (they are identities there), so the
+# data-parallel code path -- and its capture into HIP graphs -- can be exercised on a single GPU.
+FORCE_COLLECTIVES = os.environ.get("TIMEGAN_FORCE_COLLECTIVES") == "1"
+
 
 def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def multi_rank(group=None) -> bool:
+    """True when collectives have to run: more than one rank (or FORCE_COLLECTIVES with a live group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
 def rank(group=None) -> int:
@@ -38,30 +50,31 @@ class _DistSum(torch.autograd.Function):
 
 
 def dist_sum(x: torch.Tensor, group=None) -> torch.Tensor:
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return x
     return _DistSum.apply(x, group)
 
 
 def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
     """Sum the gradients of `modules` over all ranks through ONE flat bucket.  Returns bucket size."""
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return 0
     params = [p for m in modules for p in m.parameters() if p.grad is not None]
     if not params:
         return 0
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
+    views, off = [], 0
     for p in params:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        views.append(flat[off:off + n].view_as(p.grad))
         off += n
+    torch._foreach_copy_([p.grad for p in params], views)    # one multi-tensor copy, not one per parameter
     return int(flat.numel())
 
 
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:
-    if world_size(group) == 1:
+    if not multi_rank(group):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):

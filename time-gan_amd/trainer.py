@@ -12,7 +12,9 @@ from torch.optim import Adam
 
 from . import losses
 from .modules import build_networks
-from .parallel import all_reduce_grads, broadcast_parameters, world_size
+import torch.distributed as dist
+
+from .parallel import all_reduce_grads, broadcast_parameters, multi_rank
 
 
 class _GraphedStep:
@@ -21,8 +23,8 @@ class _GraphedStep:
     hundreds of kernel launches.  Inputs are copied into static buffers; outputs are static tensors.
     A call with different shapes (a ragged last batch) runs eagerly."""
 
-    def __init__(self, fn, warmup: int = 2):
-        self.fn, self.warmup, self.calls = fn, warmup, 0
+    def __init__(self, fn, warmup: int = 2, capture_mode: str = "global"):
+        self.fn, self.warmup, self.calls, self.capture_mode = fn, warmup, 0, capture_mode
         self.graph, self.static_in, self.static_out, self.shapes = None, None, None, None
 
     def __call__(self, *tensors):
@@ -35,7 +37,7 @@ class _GraphedStep:
             self.static_in = [t.clone() for t in tensors]
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=self.capture_mode):
                 self.static_out = self.fn(*self.static_in)
         for s, t in zip(self.static_in, tensors):
             s.copy_(t)
@@ -49,9 +51,9 @@ class _GraphedDiscriminatorStep:
     Both are captured back to back so the update graph reads the gradient buffers the first one
     writes; eager calls (warm-up, other shapes) run both halves eagerly for the same reason."""
 
-    def __init__(self, fwd_bwd, opt_step, threshold_of, warmup: int = 2):
+    def __init__(self, fwd_bwd, opt_step, threshold_of, warmup: int = 2, capture_mode: str = "global"):
         self.fwd_bwd, self.opt_step, self.threshold_of = fwd_bwd, opt_step, threshold_of
-        self.warmup, self.calls = warmup, 0
+        self.warmup, self.calls, self.capture_mode = warmup, 0, capture_mode
         self.g_fb, self.g_step, self.static_in, self.static_out, self.shapes = None, None, None, None, None
 
     def __call__(self, x, z):
@@ -68,10 +70,10 @@ class _GraphedDiscriminatorStep:
             self.static_in = [x.clone(), z.clone()]
             torch.cuda.synchronize()
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_mode):
                 self.static_out = self.fwd_bwd(*self.static_in)
             self.g_step = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_step):
+            with torch.cuda.graph(self.g_step, capture_error_mode=self.capture_mode):
                 self.opt_step()
         self.static_in[0].copy_(x)
         self.static_in[1].copy_(z)
@@ -114,9 +116,13 @@ class TimeGANTrainer:
         broadcast_parameters(self.nets.values(), group=group)
         lr = float(cfg["system"]["lr"])
         n = self.nets
-        # HIP-graph mode: every optimiser sub-step (zero_grad + forward + backward + Adam) is one
-        # captured graph.  Single process only: the gradient all-reduce is not captured.
-        self.use_graphs = bool(use_graphs) and world_size(group) == 1 and self.device.type == "cuda"
+        # HIP-graph mode: every optimiser sub-step (zero_grad + forward + backward [+ all-reduces] + Adam)
+        # is one captured graph.  With several ranks the collectives are captured too, which needs the
+        # RCCL ("nccl") backend; every rank takes the same host-side decisions (the discriminator
+        # loss it compares with the threshold is the global one), so all ranks replay the same graphs.
+        dp = multi_rank(group)
+        self.use_graphs = (bool(use_graphs) and self.device.type == "cuda"
+                           and (not dp or dist.get_backend(group) == "nccl"))
         # On the GPU each Adam update is one fused multi-tensor kernel (torch's default foreach path
         # issues a dozen launches per update, plus one per parameter for the bias corrections when
         # the step counters live on the device, as graph capture needs them to).
@@ -132,12 +138,14 @@ class TimeGANTrainer:
         # side streams: independent networks of a sub-step become parallel branches of its graph
         self._streams = [torch.cuda.Stream(self.device)] if self.use_graphs else None
         if self.use_graphs:
-            self._g_emb = _GraphedStep(self._embedding_core)
-            self._g_sup = _GraphedStep(self._supervisor_core)
-            self._g_gen = _GraphedStep(self._joint_g_core)
-            self._g_e = _GraphedStep(self._joint_e_core)
-            self._g_d = _GraphedDiscriminatorStep(self._joint_d_fwd_bwd_core, self.opt["d"].step,
-                                                  lambda: self.d_threshold)
+            # with collectives inside, the backend's own threads touch the device during capture
+            mode = "thread_local" if dp else "global"
+            self._g_emb = _GraphedStep(self._embedding_core, capture_mode=mode)
+            self._g_sup = _GraphedStep(self._supervisor_core, capture_mode=mode)
+            self._g_gen = _GraphedStep(self._joint_g_core, capture_mode=mode)
+            self._g_e = _GraphedStep(self._joint_e_core, capture_mode=mode)
+            self._g_d = _GraphedDiscriminatorStep(self._joint_d_fwd_bwd_core, self._d_sync_and_step,
+                                                  lambda: self.d_threshold, capture_mode=mode)
             for o in self.opt.values():
                 _init_adam_state(o)
 
@@ -205,6 +213,10 @@ class TimeGANTrainer:
                                               group=self.group, streams=self._streams)
         d_loss.backward()
         return (d_loss.detach(),)
+
+    def _d_sync_and_step(self):
+        self._sync_grads("d")
+        self.opt["d"].step()
 
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
     def embedding_step(self, x: torch.Tensor, t=None) -> float:
