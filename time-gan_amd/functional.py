@@ -197,6 +197,8 @@ def lengths_to_device(lengths, B: int, T: int, device) -> Optional[torch.Tensor]
     if len(lens) != B:
         raise RuntimeError(f"Expected `len(lengths)` to be equal to batch_size, but got {len(lens)} "
                            f"(batch_size={B})")
+    if lens.count(T) == B:      # the common case (every window has full length), checked at C speed
+        return None
     if min(lens) <= 0:
         raise RuntimeError("Length of all samples has to be greater than 0, but found an element in "
                            "'lengths' that is <= 0")
