@@ -19,6 +19,10 @@ CASES = [
     (37, 5, 10, 7, True, True),             # ragged rows, widths that are not multiples of 4
     (1, 32, 32, 32, True, True),            # a single row at the maximum width
     (100, 28, 32, 32, False, False),
+    (128 * 24, 6, 48, 24, False, True),     # generator feature MLP: F -> 2H -> H
+    (53, 30, 64, 31, True, True),           # the widest middle, odd widths around it
+    (40, 16, 33, 16, True, True),           # a middle just past two tiles
+    (16, 8, 16, 4, False, True),            # one tile everywhere
 ]
 
 
@@ -68,9 +72,10 @@ def test_head_matches_torch(case, want_dx):
 
 
 def test_head_3d_input_and_wide_fallback():
-    """(B, T, F) inputs keep their leading shape; widths above 32 run the torch modules on the GPU."""
+    """(B, T, F) inputs keep their leading shape; widths beyond the kernels' limits (32 in / out,
+    64 in the middle) run the torch modules on the GPU."""
     from timegan_amd.head import head_apply, supported
-    m = _modules(6, 48, 24, False, True, seed=0)
+    m = _modules(6, 80, 24, False, True, seed=0)
     m = {k: (None if v is None else v.to("cuda:0")) for k, v in m.items()}
     x = torch.rand(4, 5, 6, device="cuda:0")
     assert not supported(x, m["lin1"], m["lin2"])

@@ -1,50 +1,53 @@
 // Fused per-row "head" of the TimeGAN networks: the small dense stages that sit before and after
-// every GRU stack (outdated_files/TimeGANv1.py:55,67-68,145-148,226-227,294,305-306,382-383),
+// every GRU stack (outdated_files/TimeGANv1.py:39-50,55,67-68,119-128,145-148,226-227,276-287,294,
+// 305-306,382-383),
 //
 //      y = [ LayerNorm0 ] -> Linear1 -> [ LayerNorm1 -> ReLU -> Linear2 ]
 //
-// over M independent rows of at most 32 features, forward and backward, one kernel each (PyTorch
-// runs 5-8 kernels forward and about 20 backward for the same thing, each shorter than its launch).
+// over M independent rows, input and output at most 32 wide, the middle at most 64, forward and
+// backward, one kernel each (PyTorch runs 5-8 kernels forward and about 20 backward for the same
+// thing, each shorter than its launch).
 //
-// One wave owns 32 rows.  A Linear is computed TRANSPOSED on v_mfma_f32_32x32x2_f32:
-//      Y^T (feature i, row j) = W (i, k) . X^T (k, row j)
-// with W as the A operand and the activations as the B operand.  Lane (hh, j) = (lane >> 5,
-// lane & 31) then holds, for row j, the 16 features f(r, hh) = 8*(r/4) + r%4 + 4*hh, r = 0..15, of
-// the result -- and exactly that register set is the B operand of the next Linear when its k-step m
-// pairs the features f(m, 0) (lower half) and f(m, 1) (upper half).  So a whole chain of Linears,
-// LayerNorms (sum over a lane's 16 registers + one swap of the halves) and ReLUs runs in registers
-// with no shuffles.  Backward recomputes the forward from x, pushes gradients back through the
-// same scheme with transposed weight fragments, and forms the weight gradients dW = dY^T . A
-// as MFMA products contracted over the 32 rows (operands transposed through LDS).  Parameter
-// gradients leave the kernel as one partial per workgroup, summed by a second kernel in a fixed
-// order (deterministic, no atomics).
+// A wave here is alone on its SIMD and issues one instruction every ~5 cycles, so its time is its
+// instruction count.  One wave therefore owns only 16 rows and spreads each row over FOUR lanes:
+// lane (g, j) = (lane >> 4, lane & 15) holds, for row j, the features 16*ft + 4*g + r (r = 0..3) of
+// every 16-feature tile ft -- a 32-wide vector is 8 registers, and every elementwise / LayerNorm
+// step costs 8 instructions.  A Linear is computed TRANSPOSED on v_mfma_f32_16x16x4_f32,
+//      Y^T (feature i, row j) = W (i, k) . X^T (k, row j),
+// with W as the A operand and the activations as the B operand.  The reduction index of an MFMA
+// step is free to be permuted, and step s of lane group kg is made to stand for feature
+// 16*(s/4) + 4*kg + s%4 -- which is exactly register s of that lane.  So the result registers of one
+// Linear ARE the B operands of the next, and a chain of Linears, LayerNorms (in-lane sum + two
+// lane-group swaps) and ReLUs runs in registers with no shuffles.  Backward recomputes the forward
+// from x, pushes gradients back through the same scheme with transposed weight fragments, and forms
+// the weight gradients dW = dY^T . A as MFMA products contracted over the 16 rows (operands
+// transposed through LDS).  Parameter gradients leave the kernel as one partial per workgroup,
+// summed by a second kernel in a fixed order (deterministic, no atomics).
 #include "../../include/tgru.h"
 #include "tgru_internal.h"
 
 namespace tgru {
 namespace head {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kF = 32;          // feature tile
-constexpr int kTileLd = 33;     // LDS row stride of a 32x32 transpose tile
+constexpr int kIo = 32;         // widest input / output
+constexpr int kMid = 64;        // widest middle
+constexpr int kRows = 16;       // rows per wave
+constexpr int kLd = 68;         // LDS row stride of a 16 x 64 tile (16-byte aligned rows)
 
-__device__ __forceinline__ int feat(int r, int hh) { return 8 * (r >> 2) + (r & 3) + 4 * hh; }
-
-__device__ __forceinline__ void both_halves(float v, float &lo, float &hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float sum_halves(float v) {
-    float lo, hi;
-    both_halves(v, lo, hi);
-    return lo + hi;
-}
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+
+// sum of v over the four lanes (g = 0..3) that share a row; the same bits in all four
+__device__ __forceinline__ float row_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 struct Args {
     const float *x; float *y;                 // forward
@@ -54,6 +57,7 @@ struct Args {
     const float *g1, *b1, *w2, *c2;           // LayerNorm1, Linear2 (dout x dmid), bias (w2 null: shallow)
     float *slabs; long slab_stride;           // backward: one partial gradient vector per workgroup
     int M, din, dmid, dout;
+    int vec_in, vec_out;                      // rows of x/dx (y/dy) may be moved as aligned float4
     float eps;
 };
 
@@ -74,296 +78,375 @@ __host__ __device__ inline GradLayout grad_layout(int din, int dmid, int dout) {
     return g;
 }
 
-// A-operand fragments of y = W x (W is rows x cols, row-major): k-step m, lane (kh, i) -> W[i][f(m,kh)]
-__device__ __forceinline__ void load_frag(const float *w, int rows, int cols, int lane, float (&f)[16]) {
-    const int i = lane & 31, kh = lane >> 5;
+// ---- registers <-> memory ------------------------------------------------------------------------------
+// v[4*ft + r] = p[16*ft + 4*g + r] for features below n, `fill` beyond (p may be null)
+template <int NT>
+__device__ __forceinline__ void load_vec(const float *p, int n, int g, float fill, float (&v)[4 * NT]) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int k = feat(m, kh);
-        f[m] = (w && i < rows && k < cols) ? w[i * cols + k] : 0.f;
+    for (int q = 0; q < 4 * NT; ++q) {
+        const int f = 16 * (q >> 2) + 4 * g + (q & 3);
+        v[q] = (p && f < n) ? p[f] : fill;
     }
 }
-// A-operand fragments of x = W^T y: k-step m, lane (ih, k) -> W[f(m,ih)][k]
-__device__ __forceinline__ void load_frag_t(const float *w, int rows, int cols, int lane, float (&f)[16]) {
-    const int k = lane & 31, ih = lane >> 5;
+template <int NT>
+__device__ __forceinline__ void valid_mask(int n, int g, float (&v)[4 * NT]) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int i = feat(m, ih);
-        f[m] = (w && i < rows && k < cols) ? w[i * cols + k] : 0.f;
+    for (int q = 0; q < 4 * NT; ++q) v[q] = (16 * (q >> 2) + 4 * g + (q & 3)) < n ? 1.f : 0.f;
+}
+// one row per lane quartet: v = p[row*d + feature], zeros for absent rows / features
+template <int NT>
+__device__ __forceinline__ void load_rows(const float *p, int M, int d, long row, int g, bool vec, float (&v)[4 * NT]) {
+    const bool ok = row < M;
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft) {
+        const int f0 = 16 * ft + 4 * g;
+        if (vec) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && f0 < d) t = *(const float4 *)(p + row * d + f0);
+            v[4 * ft + 0] = t.x; v[4 * ft + 1] = t.y; v[4 * ft + 2] = t.z; v[4 * ft + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * ft + r] = (ok && f0 + r < d) ? p[row * d + f0 + r] : 0.f;
+        }
     }
 }
-// per-lane copy of a feature vector in register order: v[r] = p[f(r,hh)] (fill when absent / out of range)
-__device__ __forceinline__ void load_vec(const float *p, int n, int hh, float fill, float (&v)[16]) {
+template <int NT>
+__device__ __forceinline__ void store_rows(float *p, int M, int d, long row, int g, bool vec, const float (&v)[4 * NT]) {
+    if (row >= M) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f = feat(r, hh);
-        v[r] = (p && f < n) ? p[f] : fill;
+    for (int ft = 0; ft < NT; ++ft) {
+        const int f0 = 16 * ft + 4 * g;
+        if (vec) {
+            if (f0 < d) *(float4 *)(p + row * d + f0) = make_float4(v[4 * ft], v[4 * ft + 1], v[4 * ft + 2], v[4 * ft + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (f0 + r < d) p[row * d + f0 + r] = v[4 * ft + r];
+        }
     }
 }
 
-__device__ __forceinline__ f32x16 linear(const float (&wf)[16], const float (&v)[16]) {
-    f32x16 acc;
+// ---- Linear layers ---------------------------------------------------------------------------------------
+// Weight fragments are fetched apart from their use, so that a kernel can issue every parameter load
+// before the first row arrives and have the latencies overlap.
+// out = W in, W (rows x cols) row-major; `in` covers NI tiles of the cols, `out` NO tiles of the rows.
+// A operand of step s, output tile ot: lane (kg, i) -> W[16*ot + i][16*(s/4) + 4*kg + s%4].
+template <int NI, int NO>
+__device__ __forceinline__ void load_w(const float *w, int rows, int cols, int lane, float (&f)[NO][4 * NI]) {
+    const int i = lane & 15, kg = lane >> 4;
+    const bool vec = (cols & 3) == 0;     // weight rows then start 16-byte aligned (the base pointer is)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ot = 0; ot < NO; ++ot) {
+        const int o = 16 * ot + i;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) acc = mfma(wf[m], v[m], acc);
-    return acc;
+        for (int ft = 0; ft < NI; ++ft) {
+            const int k0 = 16 * ft + 4 * kg;
+            if (vec) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (w && o < rows && k0 < cols) t = *(const float4 *)(w + o * cols + k0);
+                f[ot][4 * ft + 0] = t.x; f[ot][4 * ft + 1] = t.y; f[ot][4 * ft + 2] = t.z; f[ot][4 * ft + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    f[ot][4 * ft + r] = (w && o < rows && k0 + r < cols) ? w[o * cols + k0 + r] : 0.f;
+            }
+        }
+    }
+}
+// fragments of out = W^T in, W (rows x cols): `in` covers NI tiles of the rows, `out` NO tiles of the cols.
+// A operand of step s, output tile kt: lane (ig, k) -> W[16*(s/4) + 4*ig + s%4][16*kt + k].
+template <int NI, int NO>
+__device__ __forceinline__ void load_wt(const float *w, int rows, int cols, int lane, float (&f)[NO][4 * NI]) {
+    const int k = lane & 15, ig = lane >> 4;
+#pragma unroll
+    for (int kt = 0; kt < NO; ++kt) {
+        const int c = 16 * kt + k;
+#pragma unroll
+        for (int q = 0; q < 4 * NI; ++q) {
+            const int i = 16 * (q >> 2) + 4 * ig + (q & 3);
+            f[kt][q] = (w && i < rows && c < cols) ? w[i * cols + c] : 0.f;
+        }
+    }
+}
+// out tile t = sum over steps of fragment x in; nout / nin: live widths (whole tiles beyond them are skipped)
+template <int NI, int NO>
+__device__ __forceinline__ void apply_w(const float (&f)[NO][4 * NI], int nout, int nin, const float (&in)[4 * NI],
+                                        float (&out)[4 * NO]) {
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (16 * ot < nout) {
+#pragma unroll
+            for (int ft = 0; ft < NI; ++ft)
+                if (16 * ft < nin) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma(f[ot][4 * ft + r], in[4 * ft + r], acc);
+                }
+        }
+        mfma_drain();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[4 * ot + r] = acc[r];
+    }
 }
 
-// LayerNorm statistics of one row spread over the two lane halves; entries beyond d are zero
-__device__ __forceinline__ void ln_stats(const float (&v)[16], const float (&valid)[16], int d, float eps,
+// LayerNorm statistics of one row spread over its four lanes; entries beyond d are zero on entry
+template <int NT>
+__device__ __forceinline__ void ln_stats(const float (&v)[4 * NT], const float (&valid)[4 * NT], int d, float eps,
                                          float &mean, float &rstd) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += v[r];
-    mean = sum_halves(s) / (float)d;
-    float q = 0.f;
+    for (int q = 0; q < 4 * NT; ++q) s += v[q];
+    mean = row_sum(s) / (float)d;
+    float sq = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float c = (v[r] - mean) * valid[r];
-        q += c * c;
+    for (int q = 0; q < 4 * NT; ++q) {
+        const float c = (v[q] - mean) * valid[q];
+        sq += c * c;
     }
-    rstd = rsqrtf(sum_halves(q) / (float)d + eps);
-}
-
-// rows of a tile: 32 per wave; row of lane = tile * 32 + (lane & 31)
-__device__ __forceinline__ void load_rows(const float *p, int M, int d, long row, int hh, float (&v)[16]) {
-    const bool ok = row < M;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f = feat(r, hh);
-        v[r] = (ok && f < d) ? p[row * d + f] : 0.f;
-    }
-}
-__device__ __forceinline__ void store_rows(float *p, int M, int d, long row, int hh, const float (&v)[16]) {
-    if (row >= M) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f = feat(r, hh);
-        if (f < d) p[row * d + f] = v[r];
-    }
+    rstd = rsqrtf(row_sum(sq) / (float)d + eps);
 }
 
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
+template <int NM>
 __global__ __launch_bounds__(64) void head_fwd_kernel(Args a) {
-    const int lane = threadIdx.x, hh = lane >> 5, j = lane & 31;
+    const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
-    float w1f[16], w2f[16], g0[16], b0[16], c1[16], g1[16], b1[16], c2[16], vin[16], vmid[16];
-    load_frag(a.w1, a.dmid, a.din, lane, w1f);
-    load_frag(a.w2, a.dout, a.dmid, lane, w2f);
-    load_vec(a.g0, a.din, hh, 0.f, g0);
-    load_vec(a.b0, a.din, hh, 0.f, b0);
-    load_vec(a.c1, a.dmid, hh, 0.f, c1);
-    load_vec(a.g1, a.dmid, hh, 0.f, g1);
-    load_vec(a.b1, a.dmid, hh, 0.f, b1);
-    load_vec(a.c2, a.dout, hh, 0.f, c2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        vin[r] = feat(r, hh) < a.din ? 1.f : 0.f;
-        vmid[r] = feat(r, hh) < a.dmid ? 1.f : 0.f;
-    }
-    const int ntiles = (a.M + 31) / 32;
+    // every parameter is requested before the first row: their latencies overlap with the row's
+    float w1f[NM][8], w2f[2][4 * NM], g0[8], b0[8], c1[4 * NM], g1[4 * NM], b1[4 * NM], c2[8];
+    load_w<2, NM>(a.w1, a.dmid, a.din, lane, w1f);
+    load_w<NM, 2>(a.w2, a.dout, a.dmid, lane, w2f);
+    load_vec<2>(a.g0, a.din, g, 0.f, g0);
+    load_vec<2>(a.b0, a.din, g, 0.f, b0);
+    load_vec<NM>(a.c1, a.dmid, g, 0.f, c1);
+    load_vec<NM>(a.g1, a.dmid, g, 0.f, g1);
+    load_vec<NM>(a.b1, a.dmid, g, 0.f, b1);
+    load_vec<2>(a.c2, a.dout, g, 0.f, c2);
+    const int ntiles = (a.M + kRows - 1) / kRows;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row = (long)tile * 32 + j;
-        float x[16];
-        load_rows(a.x, a.M, a.din, row, hh, x);
+        const long row = (long)tile * kRows + j;
+        float x[8];
+        load_rows<2>(a.x, a.M, a.din, row, g, a.vec_in, x);
         if (a.g0) {
-            float mean, rstd;
-            ln_stats(x, vin, a.din, a.eps, mean, rstd);
+            float vin[8], mean, rstd;
+            valid_mask<2>(a.din, g, vin);
+            ln_stats<2>(x, vin, a.din, a.eps, mean, rstd);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = ((x[r] - mean) * rstd * g0[r] + b0[r]) * vin[r];
+            for (int q = 0; q < 8; ++q) x[q] = ((x[q] - mean) * rstd * g0[q] + b0[q]) * vin[q];
         }
-        f32x16 h = linear(w1f, x);
-        mfma_drain();
-        float y[16];
+        float h[4 * NM];
+        apply_w<2, NM>(w1f, a.dmid, a.din, x, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = h[r] + c1[r];
+        for (int q = 0; q < 4 * NM; ++q) h[q] += c1[q];
+        float y[8];
         if (deep) {
-            float mean, rstd;
-            ln_stats(y, vmid, a.dmid, a.eps, mean, rstd);
+            float vmid[4 * NM], mean, rstd;
+            valid_mask<NM>(a.dmid, g, vmid);
+            ln_stats<NM>(h, vmid, a.dmid, a.eps, mean, rstd);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = fmaxf(((y[r] - mean) * rstd * g1[r] + b1[r]) * vmid[r], 0.f);
-            const f32x16 o = linear(w2f, y);
-            mfma_drain();
+            for (int q = 0; q < 4 * NM; ++q) h[q] = fmaxf(((h[q] - mean) * rstd * g1[q] + b1[q]) * vmid[q], 0.f);
+            apply_w<NM, 2>(w2f, a.dout, a.dmid, h, y);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = o[r] + c2[r];
+            for (int q = 0; q < 8; ++q) y[q] += c2[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[q] = h[q];   // a shallow head is at most 32 wide
         }
-        store_rows(a.y, a.M, a.dout, row, hh, y);
+        store_rows<2>(a.y, a.M, a.dout, row, g, a.vec_out, y);
     }
 }
 
 // ----------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------
-// F-layout registers of 32 rows -> LDS tile[row][feature]
-__device__ __forceinline__ void tile_put(float *tile, int j, int hh, const float (&v)[16]) {
+// registers of 16 rows -> LDS tile[row][feature]
+template <int NT>
+__device__ __forceinline__ void tile_put(float *tile, int j, int g, const float (&v)[4 * NT]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[j * kTileLd + feat(r, hh)] = v[r];
+    for (int ft = 0; ft < NT; ++ft)
+        *(float4 *)(tile + j * kLd + 16 * ft + 4 * g) = make_float4(v[4 * ft], v[4 * ft + 1], v[4 * ft + 2], v[4 * ft + 3]);
 }
-// operand of a product contracted over the rows: k-step m, lane (kh, c) -> tile[2m + kh][c]
-__device__ __forceinline__ void tile_get_t(const float *tile, int lane, float (&v)[16]) {
-    const int c = lane & 31, kh = lane >> 5;
+// acc[ot][kt] (o, k) += sum over the 16 rows of u[row][o] * v[row][k]; u, v given as LDS tiles.
+// step s contracts rows 4s..4s+3: lane (kg, i) reads row 4s + kg, feature 16*tile + i.
+template <int NU, int NV>
+__device__ __forceinline__ void outer_acc(const float *tu, const float *tv, int du, int dv, int lane,
+                                          f32x4 (&acc)[NU][NV]) {
+    const int i = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = tile[(2 * m + kh) * kTileLd + c];
-}
-// dW (o, k) += sum over rows of u[row][o] * v[row][k]; both given as LDS tiles
-__device__ __forceinline__ f32x16 outer_acc(const float *tu, const float *tv, int lane, f32x16 acc) {
-    float ua[16], vb[16];
-    tile_get_t(tu, lane, ua);
-    tile_get_t(tv, lane, vb);
+    for (int s = 0; s < 4; ++s) {
+        float ua[NU], vb[NV];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) acc = mfma(ua[m], vb[m], acc);
-    return acc;
+        for (int t = 0; t < NU; ++t) ua[t] = tu[(4 * s + kg) * kLd + 16 * t + i];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) vb[t] = tv[(4 * s + kg) * kLd + 16 * t + i];
+#pragma unroll
+        for (int ot = 0; ot < NU; ++ot)
+#pragma unroll
+            for (int kt = 0; kt < NV; ++kt)
+                if (16 * ot < du && 16 * kt < dv) acc[ot][kt] = mfma(ua[ot], vb[kt], acc[ot][kt]);
+    }
+    mfma_drain();
 }
-// column sums of a per-lane accumulator set: lane (hh, j) holds feature f(r,hh) of "row" j; result:
-// every lane c < 32 of the lower half returns sum over j of feature c
-__device__ __forceinline__ float colsum(float *tile, int lane, const float (&v)[16]) {
-    const int hh = lane >> 5, j = lane & 31;
-    tile_put(tile, j, hh, v);
+// dW (o, k): lane (g, jj), register r of acc[ot][kt] -> o = 16*ot + 4*g + r, k = 16*kt + jj
+template <int NU, int NV>
+__device__ __forceinline__ void store_dw(float *dst, int rows, int cols, int lane, const f32x4 (&acc)[NU][NV]) {
+    const int jj = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NU; ++ot)
+#pragma unroll
+        for (int kt = 0; kt < NV; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * ot + 4 * g + r, k = 16 * kt + jj;
+                if (o < rows && k < cols) dst[o * cols + k] = acc[ot][kt][r];
+            }
+}
+// sums a per-lane accumulator set over the 16 rows: lane f returns the total of feature f (f < 16*NT)
+template <int NT>
+__device__ __forceinline__ float colsum(float *tile, int lane, const float (&v)[4 * NT]) {
+    tile_put<NT>(tile, lane & 15, lane >> 4, v);
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) s += tile[q * kTileLd + j];
+    for (int q = 0; q < kRows; ++q) s += tile[q * kLd + lane];
     return s;
 }
 
+template <int NM>
 __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
-    __shared__ float tiles[2][32 * kTileLd];
-    const int lane = threadIdx.x, hh = lane >> 5, j = lane & 31;
+    __shared__ __align__(16) float tiles[2][kRows * kLd];
+    const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
-    float w1f[16], w1t[16], w2f[16], w2t[16], g0[16], b0[16], c1[16], g1[16], b1[16], vin[16], vmid[16];
-    load_frag(a.w1, a.dmid, a.din, lane, w1f);
-    load_frag_t(a.w1, a.dmid, a.din, lane, w1t);
-    load_frag(a.w2, a.dout, a.dmid, lane, w2f);
-    load_frag_t(a.w2, a.dout, a.dmid, lane, w2t);
-    load_vec(a.g0, a.din, hh, 0.f, g0);
-    load_vec(a.b0, a.din, hh, 0.f, b0);
-    load_vec(a.c1, a.dmid, hh, 0.f, c1);
-    load_vec(a.g1, a.dmid, hh, 0.f, g1);
-    load_vec(a.b1, a.dmid, hh, 0.f, b1);
+    f32x4 dW1[NM][2], dW2[2][NM];
+    float dc1[4 * NM], dg1[4 * NM], db1[4 * NM], dg0[8], db0[8], dc2[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        vin[r] = feat(r, hh) < a.din ? 1.f : 0.f;
-        vmid[r] = feat(r, hh) < a.dmid ? 1.f : 0.f;
-    }
-    f32x16 dW1, dW2;
-    float dc1[16], dg0[16], db0[16], dg1[16], db1[16], dc2[16];
+    for (int t = 0; t < NM; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        dW1[r] = dW2[r] = 0.f;
-        dc1[r] = dg0[r] = db0[r] = dg1[r] = db1[r] = dc2[r] = 0.f;
-    }
+        for (int u = 0; u < 2; ++u) dW1[t][u] = dW2[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4 * NM; ++q) dc1[q] = dg1[q] = db1[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dg0[q] = db0[q] = dc2[q] = 0.f;
 
-    const int ntiles = (a.M + 31) / 32;
+    // With a middle of at most 32 every weight fragment fits in registers next to the accumulators and is
+    // requested before the first row, so the latencies overlap; the 64-wide variant fetches each
+    // fragment set where it is used.
+    constexpr bool kPre = NM == 2;
+    float w1f[NM][8], w1t[2][4 * NM], w2t[NM][8], g0[8], b0[8], vin[8];
+    if (kPre) {
+        load_w<2, NM>(a.w1, a.dmid, a.din, lane, w1f);
+        load_wt<NM, 2>(a.w1, a.dmid, a.din, lane, w1t);
+        load_wt<2, NM>(a.w2, a.dout, a.dmid, lane, w2t);
+    }
+    load_vec<2>(a.g0, a.din, g, 0.f, g0);
+    load_vec<2>(a.b0, a.din, g, 0.f, b0);
+    valid_mask<2>(a.din, g, vin);
+
+    const int ntiles = (a.M + kRows - 1) / kRows;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row = (long)tile * 32 + j;
+        const long row = (long)tile * kRows + j;
         // ---- forward again, keeping what the backward needs --------------------------------------
-        float x1[16], xh0[16], rstd0 = 1.f;
-        load_rows(a.x, a.M, a.din, row, hh, x1);
+        float x1[8], xh0[8], rstd0 = 1.f;
+        load_rows<2>(a.x, a.M, a.din, row, g, a.vec_in, x1);
         if (a.g0) {
             float mean;
-            ln_stats(x1, vin, a.din, a.eps, mean, rstd0);
+            ln_stats<2>(x1, vin, a.din, a.eps, mean, rstd0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                xh0[r] = (x1[r] - mean) * rstd0 * vin[r];
-                x1[r] = (xh0[r] * g0[r] + b0[r]) * vin[r];
+            for (int q = 0; q < 8; ++q) {
+                xh0[q] = (x1[q] - mean) * rstd0 * vin[q];
+                x1[q] = (xh0[q] * g0[q] + b0[q]) * vin[q];
             }
         }
-        float dh[16];             // gradient at the output of Linear1
-        load_rows(a.dy, a.M, a.dout, row, hh, dh);
+        float dh[4 * NM];             // gradient at the output of Linear1
         if (deep) {
-            const f32x16 hacc = linear(w1f, x1);
-            mfma_drain();
-            float hn[16], act[16], rstd1, mean1;
+            float hn[4 * NM], act[4 * NM], g1[4 * NM], vmid[4 * NM], rstd1, mean1;
+            {
+                float c1[4 * NM], b1[4 * NM];
+                if (!kPre) load_w<2, NM>(a.w1, a.dmid, a.din, lane, w1f);
+                apply_w<2, NM>(w1f, a.dmid, a.din, x1, hn);
+                load_vec<NM>(a.c1, a.dmid, g, 0.f, c1);
+                load_vec<NM>(a.g1, a.dmid, g, 0.f, g1);
+                load_vec<NM>(a.b1, a.dmid, g, 0.f, b1);
+                valid_mask<NM>(a.dmid, g, vmid);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hn[r] = hacc[r] + c1[r];
-            ln_stats(hn, vmid, a.dmid, a.eps, mean1, rstd1);
+                for (int q = 0; q < 4 * NM; ++q) hn[q] += c1[q];
+                ln_stats<NM>(hn, vmid, a.dmid, a.eps, mean1, rstd1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hn[r] = (hn[r] - mean1) * rstd1 * vmid[r];
-                act[r] = fmaxf((hn[r] * g1[r] + b1[r]) * vmid[r], 0.f);
+                for (int q = 0; q < 4 * NM; ++q) {
+                    hn[q] = (hn[q] - mean1) * rstd1 * vmid[q];
+                    act[q] = fmaxf((hn[q] * g1[q] + b1[q]) * vmid[q], 0.f);
+                }
             }
             // Linear2: dc2, dW2 = dy^T . act, da = W2^T . dy
+            float dy[8], da[4 * NM];
+            load_rows<2>(a.dy, a.M, a.dout, row, g, a.vec_out, dy);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dc2[r] += dh[r];
-            tile_put(tiles[0], j, hh, dh);
-            tile_put(tiles[1], j, hh, act);
-            dW2 = outer_acc(tiles[0], tiles[1], lane, dW2);
-            const f32x16 da = linear(w2t, dh);
-            mfma_drain();
+            for (int q = 0; q < 8; ++q) dc2[q] += dy[q];
+            tile_put<2>(tiles[0], j, g, dy);
+            tile_put<NM>(tiles[1], j, g, act);
+            outer_acc<2, NM>(tiles[0], tiles[1], a.dout, a.dmid, lane, dW2);
+            if (!kPre) load_wt<2, NM>(a.w2, a.dout, a.dmid, lane, w2t);
+            apply_w<2, NM>(w2t, a.dmid, a.dout, dy, da);
             // ReLU and LayerNorm1
-            float s1 = 0.f, s2 = 0.f, dn[16];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float dpre = act[r] > 0.f ? da[r] : 0.f;
-                dg1[r] += dpre * hn[r];
-                db1[r] += dpre;
-                dn[r] = dpre * g1[r];
-                s1 += dn[r];
-                s2 += dn[r] * hn[r];
+            for (int q = 0; q < 4 * NM; ++q) {
+                const float dpre = act[q] > 0.f ? da[q] : 0.f;
+                dg1[q] += dpre * hn[q];
+                db1[q] += dpre;
+                da[q] = dpre * g1[q];
+                s1 += da[q];
+                s2 += da[q] * hn[q];
             }
-            const float m1 = sum_halves(s1) / (float)a.dmid, m2 = sum_halves(s2) / (float)a.dmid;
+            const float m1 = row_sum(s1) / (float)a.dmid, m2 = row_sum(s2) / (float)a.dmid;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dh[r] = rstd1 * (dn[r] - m1 - hn[r] * m2) * vmid[r];
+            for (int q = 0; q < 4 * NM; ++q) dh[q] = rstd1 * (da[q] - m1 - hn[q] * m2) * vmid[q];
+        } else {
+            float dy[8];
+            load_rows<2>(a.dy, a.M, a.dout, row, g, a.vec_out, dy);
+#pragma unroll
+            for (int q = 0; q < 4 * NM; ++q) dh[q] = q < 8 ? dy[q] : 0.f;
         }
         // ---- Linear1: dc1, dW1 = dh^T . x1, dx1 = W1^T . dh ------------------------------------------
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dc1[r] += dh[r];
-        tile_put(tiles[0], j, hh, dh);
-        tile_put(tiles[1], j, hh, x1);
-        dW1 = outer_acc(tiles[0], tiles[1], lane, dW1);
-        if (a.dx) {
-            const f32x16 dxa = linear(w1t, dh);
-            mfma_drain();
-            float dx[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dx[r] = dxa[r];
+        for (int q = 0; q < 4 * NM; ++q) dc1[q] += dh[q];
+        tile_put<NM>(tiles[0], j, g, dh);
+        tile_put<2>(tiles[1], j, g, x1);
+        outer_acc<NM, 2>(tiles[0], tiles[1], a.dmid, a.din, lane, dW1);
+        if (a.dx || a.g0) {
+            float dx[8];
+            if (!kPre) load_wt<NM, 2>(a.w1, a.dmid, a.din, lane, w1t);
+            apply_w<NM, 2>(w1t, a.din, a.dmid, dh, dx);
             if (a.g0) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    dg0[r] += dx[r] * xh0[r];
-                    db0[r] += dx[r];
-                    dx[r] *= g0[r];
-                    s1 += dx[r];
-                    s2 += dx[r] * xh0[r];
+                for (int q = 0; q < 8; ++q) {
+                    dg0[q] += dx[q] * xh0[q];
+                    db0[q] += dx[q];
+                    dx[q] *= g0[q];
+                    s1 += dx[q];
+                    s2 += dx[q] * xh0[q];
                 }
-                const float m1 = sum_halves(s1) / (float)a.din, m2 = sum_halves(s2) / (float)a.din;
+                const float m1 = row_sum(s1) / (float)a.din, m2 = row_sum(s2) / (float)a.din;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dx[r] = rstd0 * (dx[r] - m1 - xh0[r] * m2) * vin[r];
+                for (int q = 0; q < 8; ++q) dx[q] = rstd0 * (dx[q] - m1 - xh0[q] * m2) * vin[q];
             }
-            store_rows(a.dx, a.M, a.din, row, hh, dx);
-        } else if (a.g0) {
-            // no dx wanted, but LayerNorm0's own parameters still need the gradient at its output
-            const f32x16 dxa = linear(w1t, dh);
-            mfma_drain();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dg0[r] += dxa[r] * xh0[r];
-                db0[r] += dxa[r];
-            }
+            if (a.dx) store_rows<2>(a.dx, a.M, a.din, row, g, a.vec_in, dx);
         }
     }
-    mfma_drain();
 
     // ---- this workgroup's partial parameter gradients -------------------------------------------------
     const GradLayout gl = grad_layout(a.din, a.dmid, a.dout);
     float *slab = a.slabs + (long)blockIdx.x * a.slab_stride;
-    // dW (o, k): lane (hh, k), register r -> o = f(r, hh)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = feat(r, hh);
-        if (o < a.dmid && j < a.din) slab[gl.w1 + o * a.din + j] = dW1[r];
-        if (o < a.dout && j < a.dmid) slab[gl.w2 + o * a.dmid + j] = dW2[r];   // zeros for a shallow head
-    }
+    store_dw<NM, 2>(slab + gl.w1, a.dmid, a.din, lane, dW1);
+    store_dw<2, NM>(slab + gl.w2, a.dout, a.dmid, lane, dW2);     // zeros for a shallow head
     float s;
-    s = colsum(tiles[0], lane, dc1); if (hh == 0 && j < a.dmid) slab[gl.c1 + j] = s;
-    s = colsum(tiles[1], lane, dg0); if (hh == 0 && j < a.din) slab[gl.g0 + j] = s;
-    s = colsum(tiles[0], lane, db0); if (hh == 0 && j < a.din) slab[gl.b0 + j] = s;
-    s = colsum(tiles[1], lane, dg1); if (hh == 0 && j < a.dmid) slab[gl.g1 + j] = s;
-    s = colsum(tiles[0], lane, db1); if (hh == 0 && j < a.dmid) slab[gl.b1 + j] = s;
-    s = colsum(tiles[1], lane, dc2); if (hh == 0 && j < a.dout) slab[gl.c2 + j] = s;
+    s = colsum<NM>(tiles[0], lane, dc1); if (lane < a.dmid) slab[gl.c1 + lane] = s;
+    s = colsum<NM>(tiles[1], lane, dg1); if (lane < a.dmid) slab[gl.g1 + lane] = s;
+    s = colsum<NM>(tiles[0], lane, db1); if (lane < a.dmid) slab[gl.b1 + lane] = s;
+    s = colsum<2>(tiles[1], lane, dg0); if (lane < a.din) slab[gl.g0 + lane] = s;
+    s = colsum<2>(tiles[0], lane, db0); if (lane < a.din) slab[gl.b0 + lane] = s;
+    s = colsum<2>(tiles[1], lane, dc2); if (lane < a.dout) slab[gl.c2 + lane] = s;
 }
 
 // out[i] (=|+=) sum over workgroups of slabs[k * stride + i]: 32 elements x 8 slab groups per workgroup
@@ -374,16 +457,18 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float *slabs, lo
     const int idx = blockIdx.x * 32 + e;
     const int per = (nslabs + 7) / 8;
     const int c0 = grp * per, c1 = min(nslabs, c0 + per);
-    float v0 = 0.f, v1 = 0.f;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (idx < n) {
         int c = c0;
-        for (; c + 1 < c1; c += 2) {
+        for (; c + 3 < c1; c += 4) {
             v0 += slabs[(long)c * stride + idx];
             v1 += slabs[(long)(c + 1) * stride + idx];
+            v2 += slabs[(long)(c + 2) * stride + idx];
+            v3 += slabs[(long)(c + 3) * stride + idx];
         }
-        if (c < c1) v0 += slabs[(long)c * stride + idx];
+        for (; c < c1; ++c) v0 += slabs[(long)c * stride + idx];
     }
-    part[grp][e] = v0 + v1;
+    part[grp][e] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (grp != 0 || idx >= n) return;
     float v = 0.f;
@@ -393,9 +478,11 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float *slabs, lo
 }
 
 int workgroups(int M) {
-    const int tiles = (M + 31) / 32;
-    return tiles < 1024 ? tiles : 1024;
+    const int tiles = (M + kRows - 1) / kRows;
+    return tiles < 2048 ? tiles : 2048;
 }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace head
 }  // namespace tgru
@@ -406,10 +493,11 @@ extern "C" {
 
 static int head_check(int M, int din, int dmid, int dout, const void *w1, const void *c1, const void *w2) {
     if (M <= 0 || din <= 0 || dmid <= 0 || dout <= 0) return TGRU_E_DIMS;
-    if (din > head::kF || dmid > head::kF || dout > head::kF) return TGRU_E_DIMS;
+    if (din > head::kIo || dout > head::kIo || dmid > head::kMid) return TGRU_E_DIMS;
     if (!w2 && dout != dmid) return TGRU_E_DIMS;
-    if ((long long)M * 32 >= (1LL << 31)) return TGRU_E_DIMS;
+    if ((long long)M * 64 >= (1LL << 31)) return TGRU_E_DIMS;
     if (!w1 || !c1) return TGRU_E_NULL;
+    if (!head::aligned16(w1) || (w2 && !head::aligned16(w2))) return TGRU_E_ALIGN;
     return TGRU_OK;
 }
 
@@ -431,7 +519,11 @@ int tgru_head_forward(const float *x, float *y, int M, int din, int dmid, int do
     head::Args a{};
     a.x = x; a.y = y; a.g0 = ln0_w; a.b0 = ln0_b; a.w1 = w1; a.c1 = b1; a.g1 = ln1_w; a.b1 = ln1_b;
     a.w2 = w2; a.c2 = b2; a.M = M; a.din = din; a.dmid = dmid; a.dout = dout; a.eps = eps;
-    hipLaunchKernelGGL(head::head_fwd_kernel, dim3(head::workgroups(M)), dim3(64), 0, (hipStream_t)stream, a);
+    a.vec_in = (din % 4 == 0) && head::aligned16(x);
+    a.vec_out = (dout % 4 == 0) && head::aligned16(y);
+    const dim3 grid(head::workgroups(M)), block(64);
+    if (dmid <= 32) hipLaunchKernelGGL(head::head_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(head::head_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
 
@@ -447,10 +539,13 @@ int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int di
     head::Args a{};
     a.x = x; a.dy = dy; a.dx = dx; a.g0 = ln0_w; a.b0 = ln0_b; a.w1 = w1; a.c1 = b1; a.g1 = ln1_w;
     a.b1 = ln1_b; a.w2 = w2; a.c2 = b2; a.M = M; a.din = din; a.dmid = dmid; a.dout = dout; a.eps = eps;
+    a.vec_in = (din % 4 == 0) && head::aligned16(x) && (!dx || head::aligned16(dx));
+    a.vec_out = (dout % 4 == 0) && head::aligned16(dy);
     a.slabs = workspace; a.slab_stride = gl.total;
     const int nwg = head::workgroups(M);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(head::head_bwd_kernel, dim3(nwg), dim3(64), 0, s, a);
+    if (dmid <= 32) hipLaunchKernelGGL(head::head_bwd_kernel<2>, dim3(nwg), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(head::head_bwd_kernel<4>, dim3(nwg), dim3(64), 0, s, a);
     if (hipGetLastError() != hipSuccess) return TGRU_E_LAUNCH;
     hipLaunchKernelGGL(head::head_reduce_kernel, dim3((gl.total + 31) / 32), dim3(256), 0, s, workspace,
                        (long)gl.total, nwg, dparams, gl.total, accumulate);

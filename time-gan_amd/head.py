@@ -1,6 +1,6 @@
 """Fused dense head of the TimeGAN networks on the GPU (libtgru.so: tgru_head_forward/backward).
 
-    y = [LayerNorm] -> Linear -> [LayerNorm -> ReLU -> Linear]        (per row, widths <= 32)
+    y = [LayerNorm] -> Linear -> [LayerNorm -> ReLU -> Linear]    (per row; in / out <= 32 wide, middle <= 64)
 
 The op takes the parameters of ordinary torch modules (nn.LayerNorm, nn.Linear), so the networks
 keep torch's module structure and state_dict keys (outdated_files/TimeGANv1.py:39-50,119-128,
@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from ._lib import check, lib
 
-MAX_WIDTH = 32
+MAX_IO_WIDTH = 32
+MAX_MID_WIDTH = 64
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -84,13 +85,17 @@ class _HeadFunction(torch.autograd.Function):
 
 
 def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear]) -> bool:
-    """True when the fused kernels cover this head: GPU fp32 rows, every width <= 32, biases present."""
+    """True when the fused kernels cover this head: GPU fp32 rows, input / output at most 32 wide, the
+    middle (between the two Linears) at most 64, biases present."""
     if not x.is_cuda or x.dtype != torch.float32:
         return False
-    widths = [lin1.in_features, lin1.out_features] + ([lin2.out_features] if lin2 is not None else [])
-    if max(widths) > MAX_WIDTH or lin1.bias is None or (lin2 is not None and lin2.bias is None):
+    if lin1.bias is None or (lin2 is not None and lin2.bias is None):
         return False
-    return True
+    if lin1.in_features > MAX_IO_WIDTH:
+        return False
+    if lin2 is None:
+        return lin1.out_features <= MAX_IO_WIDTH
+    return lin1.out_features <= MAX_MID_WIDTH and lin2.out_features <= MAX_IO_WIDTH
 
 
 def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
