@@ -288,33 +288,32 @@ __device__ __forceinline__ void outer_acc(const float *tu, const float *tv, int 
     }
     mfma_drain();
 }
-// dW (o, k): lane (g, jj), register r of acc[ot][kt] -> o = 16*ot + 4*g + r, k = 16*kt + jj
+// dW (o, k): lane (g, jj), register r of acc[ot][kt] -> o = 16*ot + 4*g + r, k = 16*kt + jj.
+// Buffer stores: the lane part of the address is one register, the (ot, kt, r) part a scalar offset,
+// and an element outside the matrix gets an out-of-range lane offset, which the hardware drops.
 template <int NU, int NV>
 __device__ __forceinline__ void store_dw(float *dst, int rows, int cols, int lane, const f32x4 (&acc)[NU][NV]) {
+    constexpr int kOOB = 0x7ffffff0;
     const int jj = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, rows * cols * 4, 0x00020000);
+    const int lane_off = (4 * g * cols + jj) * 4;
 #pragma unroll
     for (int ot = 0; ot < NU; ++ot)
 #pragma unroll
-        for (int kt = 0; kt < NV; ++kt)
+        for (int r = 0; r < 4; ++r) {
+            const bool ook = 16 * ot + 4 * g + r < rows;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * ot + 4 * g + r, k = 16 * kt + jj;
-                if (o < rows && k < cols) dst[o * cols + k] = acc[ot][kt][r];
+            for (int kt = 0; kt < NV; ++kt) {
+                const bool ok = ook && 16 * kt + jj < cols;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ot][kt][r]), rs, ok ? lane_off : kOOB,
+                                                      ((16 * ot + r) * cols + 16 * kt) * 4, 0);
             }
-}
-// sums a per-lane accumulator set over the 16 rows: lane f returns the total of feature f (f < 16*NT)
-template <int NT>
-__device__ __forceinline__ float colsum(float *tile, int lane, const float (&v)[4 * NT]) {
-    tile_put<NT>(tile, lane & 15, lane >> 4, v);
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < kRows; ++q) s += tile[q * kLd + lane];
-    return s;
+        }
 }
 
 template <int NM>
 __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
-    __shared__ __align__(16) float tiles[2][kRows * kLd];
+    __shared__ __align__(16) float tiles[6][kRows * kLd];   // two operand tiles; all six for the final column sums
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
     f32x4 dW1[NM][2], dW2[2][NM];
@@ -440,13 +439,29 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
     float *slab = a.slabs + (long)blockIdx.x * a.slab_stride;
     store_dw<NM, 2>(slab + gl.w1, a.dmid, a.din, lane, dW1);
     store_dw<2, NM>(slab + gl.w2, a.dout, a.dmid, lane, dW2);     // zeros for a shallow head
-    float s;
-    s = colsum<NM>(tiles[0], lane, dc1); if (lane < a.dmid) slab[gl.c1 + lane] = s;
-    s = colsum<NM>(tiles[1], lane, dg1); if (lane < a.dmid) slab[gl.g1 + lane] = s;
-    s = colsum<NM>(tiles[0], lane, db1); if (lane < a.dmid) slab[gl.b1 + lane] = s;
-    s = colsum<2>(tiles[1], lane, dg0); if (lane < a.din) slab[gl.g0 + lane] = s;
-    s = colsum<2>(tiles[0], lane, db0); if (lane < a.din) slab[gl.b0 + lane] = s;
-    s = colsum<2>(tiles[1], lane, dc2); if (lane < a.dout) slab[gl.c2 + lane] = s;
+    // bias / LayerNorm-parameter gradients: the six per-lane accumulator sets go to LDS together and every
+    // lane f sums feature f over the 16 rows (one LDS round trip for all of them)
+    tile_put<NM>(tiles[0], j, g, dc1);
+    tile_put<NM>(tiles[1], j, g, dg1);
+    tile_put<NM>(tiles[2], j, g, db1);
+    tile_put<2>(tiles[3], j, g, dg0);
+    tile_put<2>(tiles[4], j, g, db0);
+    tile_put<2>(tiles[5], j, g, dc2);
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kRows; ++q)
+#pragma unroll
+        for (int v = 0; v < 6; ++v) s[v] += tiles[v][q * kLd + lane];
+    if (lane < a.dmid) {
+        slab[gl.c1 + lane] = s[0];
+        slab[gl.g1 + lane] = s[1];
+        slab[gl.b1 + lane] = s[2];
+    }
+    if (lane < a.din) {
+        slab[gl.g0 + lane] = s[3];
+        slab[gl.b0 + lane] = s[4];
+    }
+    if (lane < a.dout) slab[gl.c2 + lane] = s[5];
 }
 
 // out[i] (=|+=) sum over workgroups of slabs[k * stride + i]: 32 elements x 8 slab groups per workgroup
