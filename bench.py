@@ -17,7 +17,7 @@ import argparse
 import json
 import os
 import sys
-import threading
+import subprocess
 import time
 
 import torch
@@ -134,7 +134,29 @@ def device_barrier(dist, dev):
     torch.cuda.synchronize()
 
 
+def dp_graph_child():
+    """Child of a multi-rank bench process: the graph-mode training probe with its own process group.
+    Every rank prints 'DPGRAPH {json}' (the same figures: each rank times the same collective steps)."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "nccl"
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    import timegan_amd as tg
+    B, T, _, H, L, _ = WORKLOADS["c2"]
+    out = {}
+    joint_training_probe(tg, dev, 6, H, L, T, B, dist.group.WORLD, True, out)
+    device_barrier(dist, dev)
+    print("DPGRAPH " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
+    if os.environ.get("TGRU_BENCH_CHILD") == "1":
+        return dp_graph_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -278,23 +300,23 @@ def main():
         group = dist.group.WORLD if multi else None
         joint_training_probe(tg, dev, 6, H, L, T, B, group, False, joint)
         if multi:
-            # Graph replay with the RCCL all-reduces captured inside.  If a rank fails or stalls here
-            # the process group cannot be trusted any more: report what has been measured and leave.
-            def bail():
-                joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish; eager figures only"
-                emit()
-                os._exit(0)
-            guard = threading.Timer(120.0, bail)
-            guard.daemon = True
-            guard.start()
+            # Graph replay with the RCCL all-reduces captured inside has not been exercised with more than
+            # one rank where this was written, so every rank runs it in a CHILD process (the children
+            # form their own process group on the next port): whatever happens there, this process still
+            # reports what it has measured.
+            env = dict(os.environ, TGRU_BENCH_CHILD="1",
+                       MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29541")) + 17))
+            cmd = [sys.executable, "-u", os.path.abspath(__file__), "--backend", args.backend]
             try:
-                joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
-            except Exception as e:      # noqa: BLE001
-                joint["hipgraph_note"] = "graph-mode data-parallel probe failed: " + str(e)[:200]
-                emit()
-                os._exit(0)
-            device_barrier(dist, dev)
-            guard.cancel()
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DPGRAPH ")]
+                if r.returncode == 0 and lines:
+                    joint.update(json.loads(lines[-1][len("DPGRAPH "):]))
+                elif rank == 0:
+                    joint["hipgraph_note"] = ("graph-mode data-parallel probe failed (exit %d): %s"
+                                              % (r.returncode, r.stderr.strip()[-200:]))
+            except subprocess.TimeoutExpired:
+                joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish in 150 s"
         else:
             joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
     if rank == 0 and world == 1 and not args.no_cpu:
