@@ -125,12 +125,13 @@ __global__ __launch_bounds__(512) void gru_wgrad_partial_kernel(SmallWgradArgs a
 }
 
 constexpr int kRedElems = 32;    // gradient elements per workgroup of the reduce kernel
-constexpr int kRedGroups = 8;    // slab groups summed in parallel per element
+constexpr int kRedGroups = 32;   // slab groups summed in parallel per element
 
-// Stage 2: workgroup = 32 gradient elements x 8 groups of slabs.  Each thread sums its group's
-// contiguous range of partials (four interleaved sums, independent loads in flight together), the
-// eight group sums are combined in a fixed order: the result does not depend on timing.
-__global__ __launch_bounds__(256) void gru_wgrad_reduce_kernel(SmallWgradArgs a) {
+// Stage 2: workgroup = 32 gradient elements x 32 groups of slabs.  Each thread sums its group's
+// contiguous range of partials -- a handful, all loads in flight together, so the kernel costs about
+// one memory round trip -- and the group sums are combined in a fixed order: the result does not
+// depend on timing.
+__global__ __launch_bounds__(kRedElems * kRedGroups) void gru_wgrad_reduce_kernel(SmallWgradArgs a) {
     __shared__ float part[kRedGroups][kRedElems];
     const int H = a.H, L = a.L;
     const int e = threadIdx.x & (kRedElems - 1), grp = threadIdx.x / kRedElems;
@@ -158,9 +159,15 @@ __global__ __launch_bounds__(256) void gru_wgrad_reduce_kernel(SmallWgradArgs a)
     part[grp][e] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (grp != 0 || !valid) return;
-    float v = 0.f;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
-    for (int g = 0; g < kRedGroups; ++g) v += part[g][e];
+    for (int g = 0; g < kRedGroups; g += 4) {
+        u0 += part[g][e];
+        u1 += part[g + 1][e];
+        u2 += part[g + 2][e];
+        u3 += part[g + 3][e];
+    }
+    const float v = (u0 + u1) + (u2 + u3);
     if (is_w) {
         long rem = idx;
         for (int l = 0; l < L; ++l) {

@@ -464,13 +464,15 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
     if (lane < a.dout) slab[gl.c2 + lane] = s[5];
 }
 
-// out[i] (=|+=) sum over workgroups of slabs[k * stride + i]: 32 elements x 8 slab groups per workgroup
-__global__ __launch_bounds__(256) void head_reduce_kernel(const float *slabs, long stride, int nslabs, float *out,
-                                                          int n, int accumulate) {
-    __shared__ float part[8][32];
+// out[i] (=|+=) sum over workgroups of slabs[k * stride + i]: 32 elements x 32 slab groups per workgroup,
+// so a thread sums only a handful of partials with all its loads in flight together; fixed order.
+constexpr int kRedGroups = 32;
+__global__ __launch_bounds__(32 * kRedGroups) void head_reduce_kernel(const float *slabs, long stride, int nslabs,
+                                                                      float *out, int n, int accumulate) {
+    __shared__ float part[kRedGroups][32];
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + e;
-    const int per = (nslabs + 7) / 8;
+    const int per = (nslabs + kRedGroups - 1) / kRedGroups;
     const int c0 = grp * per, c1 = min(nslabs, c0 + per);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (idx < n) {
@@ -486,9 +488,15 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float *slabs, lo
     part[grp][e] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (grp != 0 || idx >= n) return;
-    float v = 0.f;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) v += part[g][e];
+    for (int g = 0; g < kRedGroups; g += 4) {
+        u0 += part[g][e];
+        u1 += part[g + 1][e];
+        u2 += part[g + 2][e];
+        u3 += part[g + 3][e];
+    }
+    const float v = (u0 + u1) + (u2 + u3);
     out[idx] = accumulate ? out[idx] + v : v;
 }
 
@@ -562,7 +570,7 @@ int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int di
     if (dmid <= 32) hipLaunchKernelGGL(head::head_bwd_kernel<2>, dim3(nwg), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(head::head_bwd_kernel<4>, dim3(nwg), dim3(64), 0, s, a);
     if (hipGetLastError() != hipSuccess) return TGRU_E_LAUNCH;
-    hipLaunchKernelGGL(head::head_reduce_kernel, dim3((gl.total + 31) / 32), dim3(256), 0, s, workspace,
+    hipLaunchKernelGGL(head::head_reduce_kernel, dim3((gl.total + 31) / 32), dim3(32 * head::kRedGroups), 0, s, workspace,
                        (long)gl.total, nwg, dparams, gl.total, accumulate);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
