@@ -154,6 +154,31 @@ def dp_graph_child():
     dist.destroy_process_group()
 
 
+def child_graph_probe(backend, rank, world, joint):
+    """Graph replay with the RCCL all-reduces captured inside has not been exercised with more than one
+    rank where this was written, so every rank runs it in a CHILD process (the children form their own
+    process group on the next port): whatever happens there, the parent still reports what it has
+    measured.  Two GPU processes per rank while it runs, so wide jobs skip it unless asked."""
+    if world > 4 and os.environ.get("TGRU_BENCH_DP_GRAPH") != "1":
+        joint["hipgraph_note"] = ("graph-mode data-parallel probe skipped at %d ranks "
+                                  "(set TGRU_BENCH_DP_GRAPH=1 to run it)" % world)
+        return
+    env = dict(os.environ, TGRU_BENCH_CHILD="1",
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29541")) + 17))
+    cmd = [sys.executable, "-u", os.path.abspath(__file__), "--backend", backend]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish in 150 s"
+        return
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DPGRAPH ")]
+    if r.returncode == 0 and lines:
+        joint.update(json.loads(lines[-1][len("DPGRAPH "):]))
+    else:
+        joint["hipgraph_note"] = ("graph-mode data-parallel probe failed (exit %d): %s"
+                                  % (r.returncode, r.stderr.strip()[-200:]))
+
+
 def main():
     if os.environ.get("TGRU_BENCH_CHILD") == "1":
         return dp_graph_child()
@@ -300,23 +325,7 @@ def main():
         group = dist.group.WORLD if multi else None
         joint_training_probe(tg, dev, 6, H, L, T, B, group, False, joint)
         if multi:
-            # Graph replay with the RCCL all-reduces captured inside has not been exercised with more than
-            # one rank where this was written, so every rank runs it in a CHILD process (the children
-            # form their own process group on the next port): whatever happens there, this process still
-            # reports what it has measured.
-            env = dict(os.environ, TGRU_BENCH_CHILD="1",
-                       MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29541")) + 17))
-            cmd = [sys.executable, "-u", os.path.abspath(__file__), "--backend", args.backend]
-            try:
-                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DPGRAPH ")]
-                if r.returncode == 0 and lines:
-                    joint.update(json.loads(lines[-1][len("DPGRAPH "):]))
-                elif rank == 0:
-                    joint["hipgraph_note"] = ("graph-mode data-parallel probe failed (exit %d): %s"
-                                              % (r.returncode, r.stderr.strip()[-200:]))
-            except subprocess.TimeoutExpired:
-                joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish in 150 s"
+            child_graph_probe(args.backend, rank, world, joint)
         else:
             joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -524,14 +524,15 @@ hipError_t launch_gru_bwd(const BwdArgs &a, hipStream_t s) {
 
 // db_ih = sums of (da_r | da_z | da_n), db_hh = sums of (da_r | da_z | da_n*r)
 // db_ih / db_hh = column sums of the per-workgroup (or per-sequence) partial sums part[nblocks][4H]
-// (columns: da_r | da_z | da_n | da_n*r).  Workgroup = 32 columns x 8 row groups; a group sums a
+// (columns: da_r | da_z | da_n | da_n*r).  Workgroup = 32 columns x 32 row groups; a group sums a
 // contiguous range of rows with four interleaved accumulators, the groups combine in fixed order.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float *part, int nblocks, int H, float *db_ih,
-                                                        float *db_hh, int accumulate) {
-    __shared__ float red[8][32];
+constexpr int kBiasGroups = 32;
+__global__ __launch_bounds__(32 * kBiasGroups) void bias_grad_kernel(const float *part, int nblocks, int H,
+                                                                     float *db_ih, float *db_hh, int accumulate) {
+    __shared__ float red[kBiasGroups][32];
     const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
-    const int per = (nblocks + 7) / 8;
+    const int per = (nblocks + kBiasGroups - 1) / kBiasGroups;
     const int k0 = grp * per, k1 = min(nblocks, k0 + per);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (i < 4 * H) {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *part, int n
     if (grp != 0 || i >= 4 * H) return;
     float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v += red[q][c];
+    for (int q = 0; q < kBiasGroups; ++q) v += red[q][c];
     if (i < 3 * H) {
         db_ih[i] = accumulate ? db_ih[i] + v : v;
         if (i < 2 * H) db_hh[i] = accumulate ? db_hh[i] + v : v;
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *part, int n
 
 hipError_t launch_bias_grad(const float *db_part, int nblocks, int H, float *db_ih, float *db_hh,
                             int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, s, db_part, nblocks, H,
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((4 * H + 31) / 32), dim3(32 * kBiasGroups), 0, s, db_part, nblocks, H,
                        db_ih, db_hh, accumulate);
     return hipGetLastError();
 }
