@@ -129,6 +129,34 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
                           int M, int N, int K, tgru_stream_t stream);
 
 /*
+ * Two independent calls evaluated together, e.g. the embedder and the generator of one training step
+ * (outdated_files/TimeGANv1.py:517-518), or the recovery and supervisor networks applied to the same
+ * latent sequence (:436-437).  The structs carry exactly the arguments of tgru_forward / tgru_backward
+ * and the results are those of the two separate calls; when both calls run on the
+ * one-sequence-per-workgroup kernels (H, In <= 32, L <= 4, B <= 1024, a padded layout) and have the same
+ * number of layers they share ONE launch -- the two stacks then run side by side on the GPU instead of
+ * one after the other.  No reference counterpart (PyTorch issues the calls one by one).
+ */
+typedef struct tgru_forward_args {
+    const float *x, *h0;
+    const int32_t *lengths, *toff;
+    const float *const *w_ih, *const *w_hh, *const *b_ih, *const *b_hh;
+    float *y, *h_n, *reserve, *workspace;
+    int B, T, In, H, L, layout;
+} tgru_forward_args;
+typedef struct tgru_backward_args {
+    const float *dy, *dh_n, *x, *h0, *y;
+    const int32_t *lengths, *toff;
+    const float *const *w_ih, *const *w_hh, *const *b_ih, *const *b_hh;
+    const float *reserve;
+    float *workspace, *dx, *dh0;
+    float *const *dw_ih, *const *dw_hh, *const *db_ih, *const *db_hh;
+    int B, T, In, H, L, layout, accumulate;
+} tgru_backward_args;
+int tgru_forward_pair(const tgru_forward_args *a, const tgru_forward_args *b, tgru_stream_t stream);
+int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b, tgru_stream_t stream);
+
+/*
  * The dense "head" the reference puts before / after every GRU stack, fused over M independent rows:
  *
  *      y = [LayerNorm(din)] -> Linear(din -> dmid) -> [LayerNorm(dmid) -> ReLU -> Linear(dmid -> dout)]

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtgru.so")
+# TGRU_LIB_PATH selects another build of the library (A/B measurements); the default is the in-tree one
+LIB_PATH = os.environ.get("TGRU_LIB_PATH") or os.path.join(_HERE, "libtgru.so")
 
 LAYOUT_TBF = 0
 LAYOUT_BTF = 1
@@ -17,6 +18,22 @@ _lib = None
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 
+
+
+class ForwardArgs(ctypes.Structure):
+    """tgru_forward_args of include/tgru.h."""
+    _fields_ = [(n, _vp) for n in ("x", "h0", "lengths", "toff", "w_ih", "w_hh", "b_ih", "b_hh",
+                                   "y", "h_n", "reserve", "workspace")] + \
+               [(n, _i) for n in ("B", "T", "In", "H", "L", "layout")]
+
+
+class BackwardArgs(ctypes.Structure):
+    """tgru_backward_args of include/tgru.h."""
+    _fields_ = [(n, _vp) for n in ("dy", "dh_n", "x", "h0", "y", "lengths", "toff", "w_ih", "w_hh", "b_ih", "b_hh",
+                                   "reserve", "workspace", "dx", "dh0", "dw_ih", "dw_hh", "db_ih", "db_hh")] + \
+               [(n, _i) for n in ("B", "T", "In", "H", "L", "layout", "accumulate")]
+
+
 # name -> (restype, argtypes); mirrors include/tgru.h one to one
 SIGNATURES = {
     "tgru_version": (_i, []),
@@ -26,6 +43,8 @@ SIGNATURES = {
     "tgru_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
     "tgru_forward": (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
     "tgru_backward": (_i, [_vp] * 19 + [_i] * 7 + [_vp]),
+    "tgru_forward_pair": (_i, [ctypes.POINTER(ForwardArgs)] * 2 + [_vp]),
+    "tgru_backward_pair": (_i, [ctypes.POINTER(BackwardArgs)] * 2 + [_vp]),
     "tgru_input_projection": (_i, [_vp] * 4 + [_i] * 3 + [_vp]),
     "tgru_head_grad_floats": (ctypes.c_size_t, [_i] * 3),
     "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),

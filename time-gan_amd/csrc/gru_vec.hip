@@ -146,10 +146,15 @@ constexpr int kBwdLoads = 2 * kVecMaxL + 2;   // direct-to-LDS loads per step
 // forward
 // ----------------------------------------------------------------------------------------------
 #define VSTAMP_BASE 0
-template <int KP>
-__global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
+template <int KP, bool PAIR>
+__global__ __launch_bounds__(320) void gru_vec_fwd_kernel(VecPair<SmallFwdArgs> ga) {
     using namespace vec;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // hb[2][L][KP] | xb[kFwdSlots][32]
+    // workgroups [0, nwg0) serve the first call of the pair, the others the second (a single call is
+    // compiled apart, so that its argument reads stay at fixed kernel-argument offsets)
+    const int set = PAIR && (int)blockIdx.x >= ga.nwg0;
+    const SmallFwdArgs &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x, nwg = set ? ga.nwg1 : ga.nwg0;
     const int H = a.H, B = a.B, T = a.T, L = a.L;
     const int lane = threadIdx.x & 63;
     const int l = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // L = the loader wave
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
         const ExtMap xm = ext_map_of(a.xmap);
         const int xstep = xm.st * a.In * 4;
-        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int b = wg; b < B; b += nwg) {
             const int len = a.lengths ? a.lengths[b] : T;
             const int xbase = lane < a.In ? (b * xm.sb * a.In + lane) * 4 : kOOB;
             auto issue = [&](int t) {   // lanes 0..31; lanes >= In and steps >= len write zeros
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
     const bool from_x = p == 0 && l == 0;
     const float *vsrc = p ? smem + l * KP : smem + (l - 1) * KP;       // + parity * L * KP
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int b = wg; b < B; b += nwg) {
         const int len = a.lengths ? a.lengths[b] : T;
         float hreg = (unit && a.h0) ? a.h0[((long)l * B + b) * H + j] : 0.f;
         if (p == 0 && j < KP) {
@@ -315,9 +320,12 @@ __global__ __launch_bounds__(320) void gru_vec_fwd_kernel(SmallFwdArgs a) {
 // ----------------------------------------------------------------------------------------------
 #undef VSTAMP_BASE
 #define VSTAMP_BASE 8
-template <int KP>
-__global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
+template <int KP, bool PAIR>
+__global__ __launch_bounds__(320) void gru_vec_bwd_kernel(VecPair<SmallBwdArgs> ga) {
     using namespace vec;
+    const int set = PAIR && (int)blockIdx.x >= ga.nwg0;
+    const SmallBwdArgs &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x, nwg = set ? ga.nwg1 : ga.nwg0;
     // gv[L][4][KP] | dxb[2][L][KP] | ops[kBwdSlots][kSlotFloats]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = a.H, B = a.B, T = a.T, L = a.L;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
         const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(a.dy_ext, tbh);
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (long)T * B * a.In * 4);
         const int gstep = B * H * 16, ystep = B * H * 4, xstep = xm.st * a.In * 4, dstep = dym.st * H * 4;
-        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        for (int b = wg; b < B; b += nwg) {
             const int len = a.lengths ? a.lengths[b] : T;
             const int gbase = j < H ? (b * H + j) * 16 : kOOB;
             const int ybase = j < H ? (b * H + j) * 4 : kOOB;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     const __amdgpu_buffer_rsrc_t rs_dx = make_rsrc(l == 0 ? a.dx_ext : nullptr, (long)T * B * a.In * 4);
     const ExtMap dxm = ext_map_of(a.dxmap);
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int b = wg; b < B; b += nwg) {
         const int len = a.lengths ? a.lengths[b] : T;
         // the gradient of h_n enters as the initial carry: steps past the length pass it through
         const long sb = ((long)l * B + b) * H + j;
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     long off = 0;
     for (int q = 0; q < l; ++q) off += 3L * H * ((q == 0 ? a.In : H) + H);
-    float *slab = a.slabs + (long)blockIdx.x * a.slab_stride + off;
+    float *slab = a.slabs + (long)wg * a.slab_stride + off;
     const __amdgpu_buffer_rsrc_t rs_slab = make_rsrc(slab, 3L * H * (In_l + H) * 4);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(SmallBwdArgs a) {
         }
     }
     if (p == 0 && unit) {
-        float *dbp = a.db_part + ((long)blockIdx.x * L + l) * 4 * H;
+        float *dbp = a.db_part + ((long)wg * L + l) * 4 * H;
 #pragma unroll
         for (int g = 0; g < 4; ++g) dbp[g * H + j] = dbs[g];
     }
@@ -542,23 +550,47 @@ bool gru_vec_supported(int B, int T, int In, int H, int L) {
     return (long)T * B * widest * 16 < (1L << 31);
 }
 
-hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s) {
+// The two calls of a pair share one launch: same layer count and the same padded width class, so the
+// block shape and the LDS layout agree; batch size, sequence length and every pointer are per call.
+bool gru_vec_pairable(int In0, int H0, int L0, int In1, int H1, int L1) {
+    return L0 == L1 && ((H0 <= 24 && In0 <= 24) == (H1 <= 24 && In1 <= 24));
+}
+
+hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, const SmallFwdArgs *second, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
-    dim3 grid(fwd_workgroups(a.B)), block(64 * (a.L + 1));
+    VecPair<SmallFwdArgs> ga{};
+    ga.g[0] = a;
+    ga.nwg0 = fwd_workgroups(a.B);
+    if (second) {
+        ga.g[1] = *second;
+        ga.nwg1 = fwd_workgroups(second->B);
+    }
+    dim3 grid(ga.nwg0 + ga.nwg1), block(64 * (a.L + 1));
     const size_t lds = (size_t)(2 * a.L * KP + vec::kFwdSlots * 32) * sizeof(float);
-    if (k24) hipLaunchKernelGGL(gru_vec_fwd_kernel<24>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gru_vec_fwd_kernel<32>, grid, block, lds, s, a);
+    if (k24 && second) hipLaunchKernelGGL((gru_vec_fwd_kernel<24, true>), grid, block, lds, s, ga);
+    else if (k24) hipLaunchKernelGGL((gru_vec_fwd_kernel<24, false>), grid, block, lds, s, ga);
+    else if (second) hipLaunchKernelGGL((gru_vec_fwd_kernel<32, true>), grid, block, lds, s, ga);
+    else hipLaunchKernelGGL((gru_vec_fwd_kernel<32, false>), grid, block, lds, s, ga);
     return hipGetLastError();
 }
 
-hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, hipStream_t s) {
+hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, const SmallBwdArgs *second, hipStream_t s) {
     const bool k24 = a.H <= 24 && a.In <= 24;
     const int KP = k24 ? 24 : 32;
-    dim3 grid(gru_vec_workgroups(a.B)), block(64 * (a.L + 1));
+    VecPair<SmallBwdArgs> ga{};
+    ga.g[0] = a;
+    ga.nwg0 = gru_vec_workgroups(a.B);
+    if (second) {
+        ga.g[1] = *second;
+        ga.nwg1 = gru_vec_workgroups(second->B);
+    }
+    dim3 grid(ga.nwg0 + ga.nwg1), block(64 * (a.L + 1));
     const size_t lds = (size_t)((4 * a.L + 2 * a.L) * KP + vec::kBwdSlots * vec::kSlotFloats) * sizeof(float);
-    if (k24) hipLaunchKernelGGL(gru_vec_bwd_kernel<24>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gru_vec_bwd_kernel<32>, grid, block, lds, s, a);
+    if (k24 && second) hipLaunchKernelGGL((gru_vec_bwd_kernel<24, true>), grid, block, lds, s, ga);
+    else if (k24) hipLaunchKernelGGL((gru_vec_bwd_kernel<24, false>), grid, block, lds, s, ga);
+    else if (second) hipLaunchKernelGGL((gru_vec_bwd_kernel<32, true>), grid, block, lds, s, ga);
+    else hipLaunchKernelGGL((gru_vec_bwd_kernel<32, false>), grid, block, lds, s, ga);
     return hipGetLastError();
 }
 

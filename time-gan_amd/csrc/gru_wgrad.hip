@@ -131,11 +131,14 @@ constexpr int kRedGroups = 32;   // slab groups summed in parallel per element
 // contiguous range of partials -- a handful, all loads in flight together, so the kernel costs about
 // one memory round trip -- and the group sums are combined in a fixed order: the result does not
 // depend on timing.
-__global__ __launch_bounds__(kRedElems * kRedGroups) void gru_wgrad_reduce_kernel(SmallWgradArgs a) {
+__global__ __launch_bounds__(kRedElems * kRedGroups) void gru_wgrad_reduce_kernel(VecPair<SmallWgradArgs> ga) {
     __shared__ float part[kRedGroups][kRedElems];
+    const int set = (int)blockIdx.x >= ga.nwg0;
+    const SmallWgradArgs &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x;
     const int H = a.H, L = a.L;
     const int e = threadIdx.x & (kRedElems - 1), grp = threadIdx.x / kRedElems;
-    const long idx = (long)blockIdx.x * kRedElems + e;
+    const long idx = (long)wg * kRedElems + e;
     const long nb = (long)L * 4 * H;
     const bool is_w = idx < a.slab_stride;
     const bool valid = idx < a.slab_stride + nb;
@@ -205,13 +208,24 @@ hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gru_wgrad_partial_kernel, dim3(a.nchunks, a.L), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_gru_small_wgrad_reduce(a, s);
+    return launch_gru_small_wgrad_reduce(a, nullptr, s);
 }
 
-hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, hipStream_t s) {
+static int reduce_workgroups(const SmallWgradArgs &a) {
     const long items = a.slab_stride + (long)a.L * 4 * a.H;
-    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)((items + kRedElems - 1) / kRedElems)),
-                       dim3(kRedElems * kRedGroups), 0, s, a);
+    return (int)((items + kRedElems - 1) / kRedElems);
+}
+
+hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, const SmallWgradArgs *second, hipStream_t s) {
+    VecPair<SmallWgradArgs> ga{};
+    ga.g[0] = a;
+    ga.nwg0 = reduce_workgroups(a);
+    if (second) {
+        ga.g[1] = *second;
+        ga.nwg1 = reduce_workgroups(*second);
+    }
+    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)(ga.nwg0 + ga.nwg1)), dim3(kRedElems * kRedGroups), 0,
+                       s, ga);
     return hipGetLastError();
 }
 

@@ -195,23 +195,46 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
     return TGRU_OK;
 }
 
+static int check_forward(const tgru_forward_args &c) {
+    int rc = check_dims(c.B, c.T, c.In, c.H, c.L, c.layout);
+    if (rc != TGRU_OK) return rc;
+    if (!c.x || !c.y || !c.workspace || !c.w_ih || !c.w_hh || !c.b_ih || !c.b_hh) return TGRU_E_NULL;
+    if (c.layout == TGRU_LAYOUT_PACKED && (!c.lengths || !c.toff)) return TGRU_E_LAYOUT;
+    if (!aligned16(c.x) || !aligned16(c.y) || !aligned16(c.workspace) || (c.reserve && !aligned16(c.reserve)) ||
+        (c.h_n && !aligned16(c.h_n)))
+        return TGRU_E_ALIGN;
+    for (int l = 0; l < c.L; ++l) {
+        if (!c.w_ih[l] || !c.w_hh[l] || !c.b_ih[l] || !c.b_hh[l]) return TGRU_E_NULL;
+        if (!aligned16(c.w_ih[l]) || !aligned16(c.w_hh[l]) || !aligned16(c.b_ih[l]) || !aligned16(c.b_hh[l]))
+            return TGRU_E_ALIGN;
+    }
+    if (c.h0 && !aligned16(c.h0)) return TGRU_E_ALIGN;
+    return TGRU_OK;
+}
+
+// arguments of the whole-stack forward kernels for one call
+static void fill_small_fwd(const tgru_forward_args &c, SmallFwdArgs &f) {
+    const Dims d{c.B, c.T, c.In, c.H, c.L, c.layout};
+    f.x = c.x; f.xmap = ext_map(d, c.toff); f.In = c.In;
+    for (int l = 0; l < c.L; ++l) {
+        f.w_ih[l] = c.w_ih[l]; f.w_hh[l] = c.w_hh[l]; f.b_ih[l] = c.b_ih[l]; f.b_hh[l] = c.b_hh[l];
+        const bool top = l == c.L - 1;
+        const bool need_int = !top || c.layout != TGRU_LAYOUT_TBF;
+        f.y_int[l] = (c.reserve && need_int) ? reserve_y(d, c.reserve, l) : nullptr;
+        f.gates[l] = c.reserve ? reserve_gates(d, c.reserve, l) : nullptr;
+    }
+    f.h0 = c.h0; f.y_ext = c.y; f.ymap = ext_map(d, c.toff); f.h_n = c.h_n; f.lengths = c.lengths;
+    f.B = c.B; f.T = c.T; f.H = c.H; f.L = c.L;
+}
+
 int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const int32_t *toff,
                  const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
                  const float *const *b_hh, float *y, float *h_n, float *reserve, float *workspace,
                  int B, int T, int In, int H, int L, int layout, tgru_stream_t stream) {
-    int rc = check_dims(B, T, In, H, L, layout);
+    const tgru_forward_args c{x, h0, lengths, toff, w_ih, w_hh, b_ih, b_hh, y, h_n, reserve, workspace,
+                              B, T, In, H, L, layout};
+    int rc = check_forward(c);
     if (rc != TGRU_OK) return rc;
-    if (!x || !y || !workspace || !w_ih || !w_hh || !b_ih || !b_hh) return TGRU_E_NULL;
-    if (layout == TGRU_LAYOUT_PACKED && (!lengths || !toff)) return TGRU_E_LAYOUT;
-    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || (reserve && !aligned16(reserve)) ||
-        (h_n && !aligned16(h_n)))
-        return TGRU_E_ALIGN;
-    for (int l = 0; l < L; ++l) {
-        if (!w_ih[l] || !w_hh[l] || !b_ih[l] || !b_hh[l]) return TGRU_E_NULL;
-        if (!aligned16(w_ih[l]) || !aligned16(w_hh[l]) || !aligned16(b_ih[l]) || !aligned16(b_hh[l]))
-            return TGRU_E_ALIGN;
-    }
-    if (h0 && !aligned16(h0)) return TGRU_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     float *gi = workspace;
@@ -220,17 +243,8 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
 
     if (use_small(In, H, L)) {
         SmallFwdArgs f{};
-        f.x = x; f.xmap = ext_map(d, toff); f.In = In;
-        for (int l = 0; l < L; ++l) {
-            f.w_ih[l] = w_ih[l]; f.w_hh[l] = w_hh[l]; f.b_ih[l] = b_ih[l]; f.b_hh[l] = b_hh[l];
-            const bool top = l == L - 1;
-            const bool need_int = !top || layout != TGRU_LAYOUT_TBF;
-            f.y_int[l] = (reserve && need_int) ? reserve_y(d, reserve, l) : nullptr;
-            f.gates[l] = reserve ? reserve_gates(d, reserve, l) : nullptr;
-        }
-        f.h0 = h0; f.y_ext = y; f.ymap = ext_map(d, toff); f.h_n = h_n; f.lengths = lengths;
-        f.B = B; f.T = T; f.H = H; f.L = L;
-        if (use_vec(B, T, In, H, L, layout)) TGRU_HIP(launch_gru_vec_fwd(f, s));
+        fill_small_fwd(c, f);
+        if (use_vec(B, T, In, H, L, layout)) TGRU_HIP(launch_gru_vec_fwd(f, nullptr, s));
         else TGRU_HIP(launch_gru_small_fwd(f, s));
         return TGRU_OK;
     }
@@ -269,26 +283,93 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
     return TGRU_OK;
 }
 
+static bool pair_on_vec(int B0, int T0, int In0, int H0, int L0, int lay0, int B1, int T1, int In1, int H1, int L1,
+                        int lay1) {
+    return use_vec(B0, T0, In0, H0, L0, lay0) && use_vec(B1, T1, In1, H1, L1, lay1) &&
+           gru_vec_pairable(In0, H0, L0, In1, H1, L1);
+}
+
+int tgru_forward_pair(const tgru_forward_args *a, const tgru_forward_args *b, tgru_stream_t stream) {
+    if (!a || !b) return TGRU_E_NULL;
+    int rc = check_forward(*a);
+    if (rc == TGRU_OK) rc = check_forward(*b);
+    if (rc != TGRU_OK) return rc;
+    if (!pair_on_vec(a->B, a->T, a->In, a->H, a->L, a->layout, b->B, b->T, b->In, b->H, b->L, b->layout)) {
+        rc = tgru_forward(a->x, a->h0, a->lengths, a->toff, a->w_ih, a->w_hh, a->b_ih, a->b_hh, a->y, a->h_n,
+                          a->reserve, a->workspace, a->B, a->T, a->In, a->H, a->L, a->layout, stream);
+        if (rc != TGRU_OK) return rc;
+        return tgru_forward(b->x, b->h0, b->lengths, b->toff, b->w_ih, b->w_hh, b->b_ih, b->b_hh, b->y, b->h_n,
+                            b->reserve, b->workspace, b->B, b->T, b->In, b->H, b->L, b->layout, stream);
+    }
+    SmallFwdArgs fa{}, fb{};
+    fill_small_fwd(*a, fa);
+    fill_small_fwd(*b, fb);
+    TGRU_HIP(launch_gru_vec_fwd(fa, &fb, (hipStream_t)stream));
+    return TGRU_OK;
+}
+
+static int check_backward(const tgru_backward_args &c) {
+    int rc = check_dims(c.B, c.T, c.In, c.H, c.L, c.layout);
+    if (rc != TGRU_OK) return rc;
+    if (!c.x || !c.y || !c.reserve || !c.workspace || !c.w_ih || !c.w_hh || !c.dw_ih || !c.dw_hh || !c.db_ih ||
+        !c.db_hh)
+        return TGRU_E_NULL;
+    if (c.layout == TGRU_LAYOUT_PACKED && (!c.lengths || !c.toff)) return TGRU_E_LAYOUT;
+    if (!aligned16(c.x) || !aligned16(c.y) || !aligned16(c.workspace) || !aligned16(c.reserve) ||
+        (c.dy && !aligned16(c.dy)) || (c.dx && !aligned16(c.dx)))
+        return TGRU_E_ALIGN;
+    for (int l = 0; l < c.L; ++l) {
+        if (!c.w_ih[l] || !c.w_hh[l] || !c.dw_ih[l] || !c.dw_hh[l] || !c.db_ih[l] || !c.db_hh[l]) return TGRU_E_NULL;
+        if (!aligned16(c.w_ih[l]) || !aligned16(c.w_hh[l])) return TGRU_E_ALIGN;
+    }
+    if ((c.h0 && !aligned16(c.h0)) || (c.dh_n && !aligned16(c.dh_n)) || (c.dh0 && !aligned16(c.dh0)))
+        return TGRU_E_ALIGN;
+    return TGRU_OK;
+}
+
+// arguments of the whole-stack backward kernels (b) and of the weight-gradient stage (g) for one call;
+// `vec`: the one-sequence-per-workgroup kernels, which leave one partial gradient per workgroup
+static void fill_small_bwd(const tgru_backward_args &c, bool vec, SmallBwdArgs &b, SmallWgradArgs &g) {
+    const Dims d{c.B, c.T, c.In, c.H, c.L, c.layout};
+    const BwdWs w = bwd_ws(d);
+    float *dg = c.workspace + w.dg;
+    float *dbp = c.workspace + w.dbp;
+    float *slabs = c.workspace + w.slabs;
+    float *res = const_cast<float *>(c.reserve);
+    const size_t dg_stride = align64(d.TB() * 4 * c.H);
+    for (int l = 0; l < c.L; ++l) {
+        const bool top = l == c.L - 1;
+        const float *y_l = (top && c.layout == TGRU_LAYOUT_TBF) ? c.y : reserve_y(d, res, l);
+        b.w_ih[l] = c.w_ih[l]; b.w_hh[l] = c.w_hh[l];
+        b.y_int[l] = y_l; b.gates[l] = reserve_gates(d, res, l);
+        b.dg[l] = dg + (size_t)l * dg_stride;
+        g.dg[l] = b.dg[l]; g.y_int[l] = y_l;
+        g.dw_ih[l] = c.dw_ih[l]; g.dw_hh[l] = c.dw_hh[l]; g.db_ih[l] = c.db_ih[l]; g.db_hh[l] = c.db_hh[l];
+    }
+    b.dy_ext = c.dy; b.dymap = ext_map(d, c.toff); b.dh_n = c.dh_n; b.h0 = c.h0;
+    b.dx_ext = c.dx; b.dxmap = ext_map(d, c.toff); b.In = c.In; b.dh0 = c.dh0; b.db_part = dbp;
+    b.lengths = c.lengths; b.B = c.B; b.T = c.T; b.H = c.H; b.L = c.L;
+    g.x = c.x; g.xmap = ext_map(d, c.toff); g.In = c.In; g.h0 = c.h0; g.db_part = dbp;
+    g.B = c.B; g.T = c.T; g.H = c.H; g.L = c.L; g.accumulate = c.accumulate;
+    g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(c.In, c.H, c.L);
+    if (vec) {
+        b.x = c.x; b.xmap = ext_map(d, c.toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
+        g.nblk = gru_vec_workgroups(c.B); g.nchunks = g.nblk;
+    } else {
+        g.nblk = gru_batch_blocks(c.B); g.nchunks = small_wgrad_chunks(c.B, c.T);
+    }
+}
+
 int tgru_backward(const float *dy, const float *dh_n, const float *x, const float *h0, const float *y,
                   const int32_t *lengths, const int32_t *toff, const float *const *w_ih,
                   const float *const *w_hh, const float *const *b_ih, const float *const *b_hh,
                   const float *reserve, float *workspace, float *dx, float *dh0, float *const *dw_ih,
                   float *const *dw_hh, float *const *db_ih, float *const *db_hh, int B, int T, int In,
                   int H, int L, int layout, int accumulate, tgru_stream_t stream) {
-    (void)b_ih; (void)b_hh;
-    int rc = check_dims(B, T, In, H, L, layout);
+    const tgru_backward_args c{dy, dh_n, x, h0, y, lengths, toff, w_ih, w_hh, b_ih, b_hh, reserve, workspace,
+                               dx, dh0, dw_ih, dw_hh, db_ih, db_hh, B, T, In, H, L, layout, accumulate};
+    int rc = check_backward(c);
     if (rc != TGRU_OK) return rc;
-    if (!x || !y || !reserve || !workspace || !w_ih || !w_hh || !dw_ih || !dw_hh || !db_ih || !db_hh)
-        return TGRU_E_NULL;
-    if (layout == TGRU_LAYOUT_PACKED && (!lengths || !toff)) return TGRU_E_LAYOUT;
-    if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || !aligned16(reserve) ||
-        (dy && !aligned16(dy)) || (dx && !aligned16(dx)))
-        return TGRU_E_ALIGN;
-    for (int l = 0; l < L; ++l) {
-        if (!w_ih[l] || !w_hh[l] || !dw_ih[l] || !dw_hh[l] || !db_ih[l] || !db_hh[l]) return TGRU_E_NULL;
-        if (!aligned16(w_ih[l]) || !aligned16(w_hh[l])) return TGRU_E_ALIGN;
-    }
-    if ((h0 && !aligned16(h0)) || (dh_n && !aligned16(dh_n)) || (dh0 && !aligned16(dh0))) return TGRU_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     const BwdWs w = bwd_ws(d);
@@ -304,34 +385,15 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     if (use_small(In, H, L)) {
         SmallBwdArgs b{};
         SmallWgradArgs g{};
-        const size_t dg_stride = align64(d.TB() * 4 * H);
-        for (int l = 0; l < L; ++l) {
-            const bool top = l == L - 1;
-            const float *y_l = (top && layout == TGRU_LAYOUT_TBF) ? y : reserve_y(d, res, l);
-            b.w_ih[l] = w_ih[l]; b.w_hh[l] = w_hh[l];
-            b.y_int[l] = y_l; b.gates[l] = reserve_gates(d, res, l);
-            b.dg[l] = dg + (size_t)l * dg_stride;
-            g.dg[l] = b.dg[l]; g.y_int[l] = y_l;
-            g.dw_ih[l] = dw_ih[l]; g.dw_hh[l] = dw_hh[l]; g.db_ih[l] = db_ih[l]; g.db_hh[l] = db_hh[l];
-        }
-        b.dy_ext = dy; b.dymap = ext_map(d, toff); b.dh_n = dh_n; b.h0 = h0;
-        b.dx_ext = dx; b.dxmap = ext_map(d, toff); b.In = In; b.dh0 = dh0; b.db_part = dbp;
-        b.lengths = lengths; b.B = B; b.T = T; b.H = H; b.L = L;
-        g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp;
-        g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
-        g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(In, H, L);
-        if (use_vec(B, T, In, H, L, layout)) {
+        const bool vec = use_vec(B, T, In, H, L, layout);
+        fill_small_bwd(c, vec, b, g);
+        if (vec) {
             // the backward kernel accumulates the weight gradients itself: one partial per workgroup
-            b.x = x; b.xmap = ext_map(d, toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
-            TGRU_HIP(launch_gru_vec_bwd(b, s));
-            g.nblk = gru_vec_workgroups(B); g.nchunks = g.nblk;
-            TGRU_HIP(launch_gru_small_wgrad_reduce(g, s));
+            TGRU_HIP(launch_gru_vec_bwd(b, nullptr, s));
+            TGRU_HIP(launch_gru_small_wgrad_reduce(g, nullptr, s));
             return TGRU_OK;
         }
         TGRU_HIP(launch_gru_small_bwd(b, s));
-        g.x = x; g.xmap = ext_map(d, toff); g.In = In; g.h0 = h0; g.db_part = dbp; g.nblk = nblk;
-        g.B = B; g.T = T; g.H = H; g.L = L; g.accumulate = accumulate;
-        g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(In, H, L); g.nchunks = small_wgrad_chunks(B, T);
         TGRU_HIP(launch_gru_small_wgrad(g, s));
         return TGRU_OK;
     }
@@ -417,6 +479,31 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             TGRU_HIP(launch_gemm(g, true, false, 1, s));
         }
     }
+    return TGRU_OK;
+}
+
+int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b, tgru_stream_t stream) {
+    if (!a || !b) return TGRU_E_NULL;
+    int rc = check_backward(*a);
+    if (rc == TGRU_OK) rc = check_backward(*b);
+    if (rc != TGRU_OK) return rc;
+    if (!pair_on_vec(a->B, a->T, a->In, a->H, a->L, a->layout, b->B, b->T, b->In, b->H, b->L, b->layout)) {
+        const tgru_backward_args *both[2] = {a, b};
+        for (const tgru_backward_args *c : both) {
+            rc = tgru_backward(c->dy, c->dh_n, c->x, c->h0, c->y, c->lengths, c->toff, c->w_ih, c->w_hh, c->b_ih,
+                               c->b_hh, c->reserve, c->workspace, c->dx, c->dh0, c->dw_ih, c->dw_hh, c->db_ih,
+                               c->db_hh, c->B, c->T, c->In, c->H, c->L, c->layout, c->accumulate, stream);
+            if (rc != TGRU_OK) return rc;
+        }
+        return TGRU_OK;
+    }
+    SmallBwdArgs ba{}, bb{};
+    SmallWgradArgs ga{}, gb{};
+    fill_small_bwd(*a, true, ba, ga);
+    fill_small_bwd(*b, true, bb, gb);
+    hipStream_t s = (hipStream_t)stream;
+    TGRU_HIP(launch_gru_vec_bwd(ba, &bb, s));
+    TGRU_HIP(launch_gru_small_wgrad_reduce(ga, &gb, s));
     return TGRU_OK;
 }
 

@@ -169,7 +169,8 @@ struct SmallWgradArgs {
     int B, T, H, L, accumulate;
 };
 hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s);
-hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, hipStream_t s);   // stage 2 alone
+hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, const SmallWgradArgs *second,
+                                         hipStream_t s);   // stage 2 alone, for one call or a pair
 long small_wgrad_slab_floats(int In, int H, int L);
 int small_wgrad_chunks(int B, int T);
 
@@ -192,8 +193,15 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
 
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
-hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, hipStream_t s);
-hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, hipStream_t s);
+// Two independent calls in one launch: workgroups [0, nwg0) serve g[0], the others g[1] (nwg1 may be 0).
+template <typename A>
+struct VecPair {
+    A g[2];
+    int nwg0, nwg1;
+};
+bool gru_vec_pairable(int In0, int H0, int L0, int In1, int H1, int L1);
+hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, const SmallFwdArgs *second, hipStream_t s);
+hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, const SmallBwdArgs *second, hipStream_t s);
 int gru_vec_workgroups(int B);
 bool gru_vec_supported(int B, int T, int In, int H, int L);
 

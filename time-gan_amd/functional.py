@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib
+from ._lib import BackwardArgs, ForwardArgs, LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -116,6 +116,107 @@ class _GRUFunction(torch.autograd.Function):
                                   B, T, In, H, L, layout, 0, _stream(dev))
             check(rc, "tgru_backward")
         return (dx, dh0, None, None, None, None, None, *grads)
+
+
+def _addr(t) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _GRUPairFunction(torch.autograd.Function):
+    """(yA, h_nA, yB, h_nB) = two independent GRU calls through tgru_forward_pair / tgru_backward_pair:
+    when both run on the one-sequence-per-workgroup kernels they share one launch forward and one
+    backward (the two stacks run side by side on the GPU).  `specs` = ((B, T, layout), (B, T, layout));
+    `tensors` = x, h0, lengths, toff, *weights of call A, then the same of call B."""
+
+    @staticmethod
+    def forward(ctx, specs, *tensors):
+        nw = (len(tensors) - 8) // 2
+        calls = []
+        for k in range(2):
+            x, h0, lengths, toff, *weights = tensors[k * (4 + nw):(k + 1) * (4 + nw)]
+            B, T, layout = specs[k]
+            _require_gpu(x, "input")
+            In, H, L = _dims(x, layout, B, T, weights)
+            calls.append(dict(x=x.contiguous(), h0=None if h0 is None else h0.contiguous(), lengths=lengths,
+                              toff=toff, weights=tuple(w.contiguous() for w in weights), B=B, T=T, In=In, H=H,
+                              L=L, layout=layout))
+        dev = calls[0]["x"].device
+        need_grad = any(ctx.needs_input_grad)
+        keep, args = [], []
+        with torch.cuda.device(dev):
+            lb = lib()
+            for c in calls:
+                B, T, In, H, L, layout = (c[k] for k in ("B", "T", "In", "H", "L", "layout"))
+                f32 = dict(device=dev, dtype=torch.float32)
+                c["y"] = torch.empty(c["x"].shape[:-1] + (H,), **f32)
+                c["h_n"] = torch.empty((L, B, H), **f32)
+                ws = torch.empty(lb.tgru_forward_workspace_bytes(B, T, In, H, L) // 4, **f32)
+                c["reserve"] = torch.empty(lb.tgru_reserve_bytes(B, T, In, H, L, layout) // 4, **f32) \
+                    if need_grad else None
+                arrays = [_ptr_array(g) for g in _split_weights(c["weights"], L)]
+                keep += arrays + [ws]
+                args.append(ForwardArgs(_addr(c["x"]), _addr(c["h0"]), _addr(c["lengths"]), _addr(c["toff"]),
+                                        *[ctypes.cast(a, ctypes.c_void_p) for a in arrays],
+                                        _addr(c["y"]), _addr(c["h_n"]), _addr(c["reserve"]), _addr(ws),
+                                        B, T, In, H, L, layout))
+            check(lb.tgru_forward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                  "tgru_forward_pair")
+        ctx.set_materialize_grads(False)
+        ctx.meta = [tuple(c[k] for k in ("B", "T", "In", "H", "L", "layout")) + (c["h0"] is not None,)
+                    for c in calls]
+        ctx.nw = nw
+        saved = []
+        for c in calls:
+            saved += [c["x"], c["h0"], c["y"], c["lengths"], c["toff"], c["reserve"], *c["weights"]]
+        ctx.save_for_backward(*saved)
+        return calls[0]["y"], calls[0]["h_n"], calls[1]["y"], calls[1]["h_n"]
+
+    @staticmethod
+    def backward(ctx, *douts):
+        nw = ctx.nw
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        keep, args, results = [], [], []
+        with torch.cuda.device(dev):
+            lb = lib()
+            for k in range(2):
+                x, h0, y, lengths, toff, reserve, *weights = saved[k * (6 + nw):(k + 1) * (6 + nw)]
+                B, T, In, H, L, layout, has_h0 = ctx.meta[k]
+                dy, dh_n = douts[2 * k], douts[2 * k + 1]
+                dy = torch.zeros_like(y) if dy is None else dy.contiguous()
+                dh_n = None if dh_n is None else dh_n.contiguous()
+                base = 1 + k * (4 + nw)          # position of this call's x among the forward inputs
+                ws = torch.empty(lb.tgru_backward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
+                                 dtype=torch.float32)
+                dx = torch.empty_like(x) if ctx.needs_input_grad[base] else None
+                dh0 = torch.empty_like(h0) if (has_h0 and ctx.needs_input_grad[base + 1]) else None
+                grads = [torch.empty_like(w) for w in weights]
+                arrays = [_ptr_array(g) for g in _split_weights(weights, L)] + \
+                         [_ptr_array(g) for g in _split_weights(grads, L)]
+                keep += arrays + [ws, dy, dh_n]
+                cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays]
+                args.append(BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths),
+                                         _addr(toff), *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0),
+                                         *cast[4:], B, T, In, H, L, layout, 0))
+                results.append((dx, dh0, grads))
+            check(lb.tgru_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                  "tgru_backward_pair")
+        out = [None]
+        for dx, dh0, grads in results:
+            out += [dx, dh0, None, None, *grads]
+        return tuple(out)
+
+
+def gru_apply_pair(call_a, call_b):
+    """Two independent differentiable GRU calls evaluated together.  Each call is a tuple
+    (x, weights, B, T, layout, h0, lengths, toff) with gru_apply's meaning; the weight lists must
+    have the same length (same number of layers).  Returns ((yA, h_nA), (yB, h_nB))."""
+    specs, tensors = [], []
+    for x, weights, B, T, layout, h0, lengths, toff in (call_a, call_b):
+        specs.append((B, T, layout))
+        tensors += [x, h0, lengths, toff, *weights]
+    ya, ha, yb, hb = _GRUPairFunction.apply(tuple(specs), *tensors)
+    return (ya, ha), (yb, hb)
 
 
 def gru_apply(x: torch.Tensor, weights: Sequence[torch.Tensor], B: int, T: int, layout: int,

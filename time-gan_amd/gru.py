@@ -115,3 +115,23 @@ class GRU(nn.Module):
             raise RuntimeError(f"Expected hidden size {(L, B, H)}, got {list(hx.shape)}")
         lens_dev = F_.lengths_to_device(lengths, B, T, input.device)
         return F_.gru_apply(input, weights, B, T, layout, h0=hx, lengths=lens_dev)
+
+
+def gru_pair(rnn_a: "GRU", x_a: torch.Tensor, lengths_a, rnn_b: "GRU", x_b: torch.Tensor, lengths_b):
+    """(y_a, y_b) = (rnn_a(x_a, lengths=lengths_a)[0], rnn_b(x_b, lengths=lengths_b)[0]) for two INDEPENDENT
+    stacks, evaluated together: with the same number of layers and hidden sizes of at most 32 both run in
+    one kernel launch, forward and backward (F_.gru_apply_pair).  Padded (B,T,F) / (T,B,F) inputs only."""
+    calls = []
+    for rnn, x, lengths in ((rnn_a, x_a, lengths_a), (rnn_b, x_b, lengths_b)):
+        rnn._check_dropout()
+        if x.dim() != 3 or x.shape[-1] != rnn.input_size:
+            raise RuntimeError(f"gru_pair: expected a 3D input with {rnn.input_size} features, got {tuple(x.shape)}")
+        if rnn.batch_first:
+            B, T, layout = x.shape[0], x.shape[1], LAYOUT_BTF
+        else:
+            T, B, layout = x.shape[0], x.shape[1], LAYOUT_TBF
+        calls.append((x, rnn._flat_weights, B, T, layout, None, F_.lengths_to_device(lengths, B, T, x.device), None))
+    if rnn_a.num_layers != rnn_b.num_layers:
+        return rnn_a(x_a, lengths=lengths_a)[0], rnn_b(x_b, lengths=lengths_b)[0]
+    (y_a, _), (y_b, _) = F_.gru_apply_pair(calls[0], calls[1])
+    return y_a, y_b

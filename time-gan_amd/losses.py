@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import loss_ops
+from .modules import forward_pair
 from .parallel import dist_sum, multi_rank
 
 
@@ -64,39 +65,25 @@ def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Te
     return c + m1, torch.sqrt(torch.clamp(m2 - m1 * m1, min=0.0))
 
 
-def _fork_join(fns, streams):
-    """Evaluates independent callables; with `streams` (side HIP streams, used while a sub-step is
-    captured into a graph) the second and later ones run on their own stream between a fork and a
-    join on the current stream, so independent networks become parallel branches of the graph.
-    Autograd replays each branch's backward on the stream its forward ran on."""
-    if not streams or len(fns) == 1:
-        return [f() for f in fns]
-    cur = torch.cuda.current_stream()
-    outs = [None] * len(fns)
-    side = list(streams[:len(fns) - 1])
-    for s in side:
-        s.wait_stream(cur)
-    outs[0] = fns[0]()
-    for i, s in enumerate(side):
-        with torch.cuda.stream(s):
-            outs[i + 1] = fns[i + 1]()
-    for s in side:
-        cur.wait_stream(s)
-    return outs
+def _batched(inputs, t):
+    """The inputs of several same-weight calls as ONE batch, or None when lengths are ragged (a
+    concatenation of sorted length lists is not sorted): (concatenated input, its lengths, the sizes)."""
+    T = inputs[0].shape[1]
+    lens = [int(v) for v in t]
+    if len(inputs) == 1 or any(v != T for v in lens):
+        return None
+    return torch.cat(inputs, dim=0), lens * len(inputs), [u.shape[0] for u in inputs]
 
 
 def _apply_batched(net, inputs, t):
     """net(u, t) for each u in `inputs`, evaluated as ONE call on the concatenated batch when every
     sequence has full length (rows of a batch never interact inside a network, so the results are
     those of the separate calls the reference makes, e.g. d(h), d(_h), d(_e) at TimeGANv1.py:493-495;
-    the weight gradients come out already summed).  Ragged lengths keep separate calls, because a
-    concatenation of sorted length lists is not sorted."""
-    T = inputs[0].shape[1]
-    lens = [int(v) for v in t]
-    if len(inputs) == 1 or any(v != T for v in lens):
+    the weight gradients come out already summed).  Ragged lengths keep separate calls."""
+    both = _batched(inputs, t)
+    if both is None:
         return [net(u, t) for u in inputs]
-    out = net(torch.cat(inputs, dim=0), lens * len(inputs))
-    return out.split([u.shape[0] for u in inputs], dim=0)
+    return net(both[0], both[1]).split(both[2], dim=0)
 
 
 def embedding_forward_side(emb, rec, x, t, group=None):
@@ -110,10 +97,10 @@ def embedding_forward_side(emb, rec, x, t, group=None):
     return 10 * torch.sqrt(e_loss_t0), x_tilde
 
 
-def embedding_forward_main(emb, sup, rec, x, t, group=None, streams=None):
+def embedding_forward_main(emb, sup, rec, x, t, group=None):
     """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0)."""
     h = emb(x, t)
-    x_tilde, h_sup = _fork_join([lambda: rec(h, t), lambda: sup(h, t)], streams)
+    x_tilde, h_sup = forward_pair(rec, h, t, sup, h, t)
     out = _fused(loss_ops.EMBED_MAIN, [x_tilde, x, h_sup, h], x, h, group=group)
     if out is not None:
         return out
@@ -133,13 +120,11 @@ def supervisor_forward(emb, sup, x, t, group=None):
     return _mse(h_sup[:, :-1, :], h[:, 1:, :], group), h, h_sup
 
 
-def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None, streams=None):
+def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
     """TimeGANv1.py:475-503 -> d_loss.  Only the discriminator receives gradients."""
     with torch.no_grad():   # the reference detaches all three (TimeGANv1.py:486-491): nothing to save for backward
-        def real_branch():
-            h_ = emb(x, t)
-            return h_, sup(h_, t)
-        (h, h_hat), e_hat = _fork_join([real_branch, lambda: g(z, t)], streams)
+        h, e_hat = forward_pair(emb, x, t, g, z, t)
+        h_hat = sup(h, t)
     y_real, y_fake, y_fake_e = _apply_batched(d, [h, h_hat, e_hat], t)
     out = _fused(loss_ops.DISCRIMINATOR, [y_real, y_fake, y_fake_e], None, h, gamma, group)
     if out is not None:
@@ -150,16 +135,21 @@ def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None, stream
     return d_loss_fake + d_loss_real + gamma * d_loss_fake_e
 
 
-def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None, streams=None):
+def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None):
     """TimeGANv1.py:506-553 -> g_loss.
 
     The reference also evaluates rec(h) at :521 and overwrites the result at :528 before any use;
     that forward contributes nothing to the loss or to any gradient and is not evaluated here.
     """
-    h, e_hat = _fork_join([lambda: emb(x, t), lambda: g(z, t)], streams)
+    h, e_hat = forward_pair(emb, x, t, g, z, t)
     h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
-    x_hat, (y_fake, y_fake_e) = _fork_join([lambda: rec(h_hat, t),
-                                            lambda: _apply_batched(d, [h_hat, e_hat], t)], streams)
+    both = _batched([h_hat, e_hat], t)
+    if both is None:
+        x_hat = rec(h_hat, t)
+        y_fake, y_fake_e = d(h_hat, t), d(e_hat, t)
+    else:
+        x_hat, y = forward_pair(rec, h_hat, t, d, both[0], both[1])
+        y_fake, y_fake_e = y.split(both[2], dim=0)
     out = _fused(loss_ops.GENERATOR, [y_fake, y_fake_e, h_sup, h, x_hat, x], x, h, gamma, group)
     if out is not None:
         return out[0]

@@ -19,12 +19,19 @@ from typing import Dict, Sequence
 import torch
 import torch.nn as nn
 
-from .gru import GRU
+from .gru import GRU, gru_pair
 from .head import head_apply
 
 
 class _RecurrentBlock(nn.Module):
-    """Shared forward plumbing: [mlp] -> GRU over valid steps -> LayerNorm -> head."""
+    """Shared forward plumbing: pre (the feature MLP, if any) -> GRU over valid steps -> post (LayerNorm
+    and the output layers).  Subclasses define `pre` / `post` and name their GRU in `_rnn_name`."""
+
+    def pre(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+    def forward(self, x: torch.Tensor, t) -> torch.Tensor:
+        return self.post(self._run_rnn(getattr(self, self._rnn_name), self.pre(x), t))
 
     def _run_rnn(self, rnn: nn.Module, x: torch.Tensor, t) -> torch.Tensor:
         if isinstance(rnn, GRU):
@@ -74,8 +81,10 @@ class Embedding(_RecurrentBlock):
 
     _rnn_name = "emb_rnn"
 
-    def forward(self, x: torch.Tensor, t) -> torch.Tensor:
-        h = self._run_rnn(self.emb_rnn, self._head(x, None, self.mlp[0], self.mlp[1:]), t)
+    def pre(self, x: torch.Tensor) -> torch.Tensor:
+        return self._head(x, None, self.mlp[0], self.mlp[1:])
+
+    def post(self, h: torch.Tensor) -> torch.Tensor:
         return self._head(h, self.norm, self.emb_linear)
 
 
@@ -97,8 +106,8 @@ class Recovery(_RecurrentBlock):
 
     _rnn_name = "rec_rnn"
 
-    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self._head(self._run_rnn(self.rec_rnn, h, t), self.norm, self.mlp[0], self.mlp[1:])
+    def post(self, h: torch.Tensor) -> torch.Tensor:
+        return self._head(h, self.norm, self.mlp[0], self.mlp[1:])
 
 
 class Supervisor(_RecurrentBlock):
@@ -118,8 +127,8 @@ class Supervisor(_RecurrentBlock):
 
     _rnn_name = "sup_rnn"
 
-    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self._head(self._run_rnn(self.sup_rnn, h, t), self.norm, self.mlp[0], self.mlp[1:])
+    def post(self, h: torch.Tensor) -> torch.Tensor:
+        return self._head(h, self.norm, self.mlp[0], self.mlp[1:])
 
 
 class Generator(_RecurrentBlock):
@@ -141,8 +150,10 @@ class Generator(_RecurrentBlock):
 
     _rnn_name = "g_rnn"
 
-    def forward(self, z: torch.Tensor, t) -> torch.Tensor:
-        h = self._run_rnn(self.g_rnn, self._head(z, None, self.mlp[0], self.mlp[1:]), t)
+    def pre(self, z: torch.Tensor) -> torch.Tensor:
+        return self._head(z, None, self.mlp[0], self.mlp[1:])
+
+    def post(self, h: torch.Tensor) -> torch.Tensor:
         return self._head(h, self.norm, self.g_linear)
 
 
@@ -162,8 +173,23 @@ class Discriminator(_RecurrentBlock):
 
     _rnn_name = "d_rnn"
 
-    def forward(self, h: torch.Tensor, t) -> torch.Tensor:
-        return self._head(self._run_rnn(self.d_rnn, h, t), self.norm, self.mlp[0])
+    def post(self, h: torch.Tensor) -> torch.Tensor:
+        return self._head(h, self.norm, self.mlp[0])
+
+
+def forward_pair(net_a: _RecurrentBlock, x_a: torch.Tensor, t_a, net_b: _RecurrentBlock, x_b: torch.Tensor, t_b):
+    """(net_a(x_a, t_a), net_b(x_b, t_b)) for two networks that do not depend on each other (the embedder
+    and the generator of one step, TimeGANv1.py:517-518; recovery and supervisor on the same latent
+    sequence, :436-437): their GRU stacks run in ONE kernel launch, forward and backward, side by side
+    on the GPU.  Anything the paired kernels do not cover falls back to the two separate calls."""
+    rnn_a, rnn_b = getattr(net_a, net_a._rnn_name), getattr(net_b, net_b._rnn_name)
+    pairable = (isinstance(rnn_a, GRU) and isinstance(rnn_b, GRU) and x_a.is_cuda and x_b.is_cuda
+                and net_a.padding_value == 0 and net_b.padding_value == 0
+                and rnn_a.num_layers == rnn_b.num_layers)
+    if not pairable:
+        return net_a(x_a, t_a), net_b(x_b, t_b)
+    h_a, h_b = gru_pair(rnn_a, net_a.pre(x_a), t_a, rnn_b, net_b.pre(x_b), t_b)
+    return net_a.post(h_a), net_b.post(h_b)
 
 
 def build_networks(cfg: Dict, rnn_cls=GRU) -> Dict[str, nn.Module]:

@@ -135,8 +135,6 @@ class TimeGANTrainer:
                     "g": Adam(n["g"].parameters(), lr=lr, **kw_opt), "d": Adam(n["d"].parameters(), lr=lr, **kw_opt)}
         self.d_threshold = float(cfg["d"]["threshold"])
         self.seq_len = int(cfg["system"]["seq_len"])
-        # side streams: independent networks of a sub-step become parallel branches of its graph
-        self._streams = [torch.cuda.Stream(self.device)] if self.use_graphs else None
         if self.use_graphs:
             # with collectives inside, the backend's own threads touch the device during capture
             mode = "thread_local" if dp else "global"
@@ -185,7 +183,7 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup", "g", "d")
         g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
-                                          group=self.group, streams=self._streams)
+                                          group=self.group)
         g_loss.backward()
         self._sync_grads("g", "sup")
         self.opt["g"].step()
@@ -196,7 +194,7 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup")
         e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
-                                                     group=self.group, streams=self._streams)
+                                                     group=self.group)
         e_loss.backward()
         self._sync_grads("emb", "rec")
         self.opt["emb_main"].step()
@@ -210,7 +208,7 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
-                                              group=self.group, streams=self._streams)
+                                              group=self.group)
         d_loss.backward()
         return (d_loss.detach(),)
 
