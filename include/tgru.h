@@ -190,6 +190,25 @@ int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int di
                        tgru_stream_t stream);
 
 /*
+ * Two independent heads in one launch (the output stages of two networks that were evaluated as a
+ * pair, see tgru_forward_pair); the fields are the arguments of tgru_head_forward / tgru_head_backward,
+ * the results those of the two separate calls.  No reference counterpart.
+ */
+typedef struct tgru_head_args {
+    const float *x;
+    float *y;                /* forward only */
+    const float *dy;         /* backward only */
+    float *dx;               /* backward only, may be NULL */
+    int M, din, dmid, dout;
+    const float *ln0_w, *ln0_b, *w1, *b1, *ln1_w, *ln1_b, *w2, *b2;
+    float eps;
+    float *dparams, *workspace;   /* backward only */
+    int accumulate;
+} tgru_head_args;
+int tgru_head_forward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream);
+int tgru_head_backward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream);
+
+/*
  * The loss expressions of the three training phases, fused (no reference FFI; they replace the
  * torch compositions at outdated_files/TimeGANv1.py:410-553):
  *   TGRU_LOSS_EMBED_SIDE     in = {x_tilde, x}                    out[0] = 10 sqrt(mse)            (:420-421)

@@ -87,3 +87,43 @@ def test_head_3d_input_and_wide_fallback():
     ref = _torch_head({k: (None if v is None else v.cpu()) for k, v in m2.items()}, x.cpu())
     assert y2.shape == (4, 5, 24)
     assert_close(y2.detach().cpu().numpy(), ref.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y 3d")
+
+
+PAIRS = [
+    ((3072, 24, 24, 24, True, False), (3072, 24, 24, 24, True, False)),   # embedder + generator output stages
+    ((3072, 24, 24, 6, True, True), (6144, 24, 24, 1, True, False)),      # recovery + discriminator (doubled batch)
+    ((3072, 6, 24, 24, False, True), (3072, 6, 48, 24, False, True)),     # the two feature MLPs, one of them wide
+    ((37, 5, 10, 7, True, True), (20, 30, 64, 31, True, True)),
+]
+
+
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: "%d_%d_%d_%d__%d_%d_%d_%d" % (p[0][:4] + p[1][:4]))
+def test_head_pair_equals_separate_calls(pair):
+    """Two heads in one launch give bit-for-bit what the two separate launches give."""
+    from timegan_amd.head import head_apply, head_apply_pair
+    mods, xs, dys = [], [], []
+    for k, (M, din, dmid, dout, ln0, deep) in enumerate(pair):
+        m = _modules(din, dmid, dout, ln0, deep, seed=17 + k)
+        mods.append({n: (None if v is None else v.to("cuda:0")) for n, v in m.items()})
+        g = torch.Generator().manual_seed(5 + k)
+        xs.append(torch.randn(M, din, generator=g).to("cuda:0"))
+        dys.append(torch.randn(M, dout, generator=g).to("cuda:0"))
+    spec = [(m["ln0"], m["lin1"], m["ln1"], m["lin2"]) for m in mods]
+
+    def run(paired):
+        for m in mods:
+            for v in m.values():
+                if v is not None:
+                    v.zero_grad()
+        xa, xb = (x.clone().requires_grad_(True) for x in xs)
+        if paired:
+            ya, yb = head_apply_pair(xa, spec[0], xb, spec[1])
+        else:
+            ya, yb = head_apply(xa, *spec[0]), head_apply(xb, *spec[1])
+        ((ya * dys[0]).sum() + (yb * dys[1]).sum()).backward()
+        grads = [p.grad.clone() for m in mods for v in m.values() if v is not None for p in v.parameters()]
+        return [ya.detach(), yb.detach(), xa.grad, xb.grad] + grads
+
+    ref, got = run(False), run(True)
+    for i, (u, v) in enumerate(zip(got, ref)):
+        assert torch.equal(u, v), f"tensor {i}: max diff {float((u - v).abs().max()):.3e}"

@@ -34,6 +34,14 @@ class BackwardArgs(ctypes.Structure):
                [(n, _i) for n in ("B", "T", "In", "H", "L", "layout", "accumulate")]
 
 
+class HeadArgs(ctypes.Structure):
+    """tgru_head_args of include/tgru.h."""
+    _fields_ = [("x", _vp), ("y", _vp), ("dy", _vp), ("dx", _vp)] + \
+               [(n, _i) for n in ("M", "din", "dmid", "dout")] + \
+               [(n, _vp) for n in ("ln0_w", "ln0_b", "w1", "b1", "ln1_w", "ln1_b", "w2", "b2")] + \
+               [("eps", ctypes.c_float), ("dparams", _vp), ("workspace", _vp), ("accumulate", _i)]
+
+
 # name -> (restype, argtypes); mirrors include/tgru.h one to one
 SIGNATURES = {
     "tgru_version": (_i, []),
@@ -50,6 +58,8 @@ SIGNATURES = {
     "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),
     "tgru_head_forward": (_i, [_vp] * 2 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp]),
     "tgru_head_backward": (_i, [_vp] * 3 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp, _vp, _i, _vp]),
+    "tgru_head_forward_pair": (_i, [ctypes.POINTER(HeadArgs)] * 2 + [_vp]),
+    "tgru_head_backward_pair": (_i, [ctypes.POINTER(HeadArgs)] * 2 + [_vp]),
     "tgru_loss_layout": (_i, [_i] * 3 + [ctypes.POINTER(ctypes.c_int64)]),
     "tgru_loss_partial": (_i, [_i, _i, _vp] + [_i] * 4 + [_vp, _vp]),
     "tgru_loss_final": (_i, [_i] * 5 + [ctypes.c_float, _vp, _vp]),

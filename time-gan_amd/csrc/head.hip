@@ -209,8 +209,13 @@ __device__ __forceinline__ void ln_stats(const float (&v)[4 * NT], const float (
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
-template <int NM>
-__global__ __launch_bounds__(64) void head_fwd_kernel(Args a) {
+// A launch serves one head or a PAIR of independent heads: workgroups [0, nwg0) the first, the others
+// the second (a single head is compiled apart so its argument reads stay at fixed offsets).
+template <int NM, bool PAIR>
+__global__ __launch_bounds__(64) void head_fwd_kernel(VecPair<Args> ga) {
+    const int set = PAIR && (int)blockIdx.x >= ga.nwg0;
+    const Args &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x, nwg = set ? ga.nwg1 : ga.nwg0;
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
     // every parameter is requested before the first row: their latencies overlap with the row's
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(Args a) {
     load_vec<NM>(a.b1, a.dmid, g, 0.f, b1);
     load_vec<2>(a.c2, a.dout, g, 0.f, c2);
     const int ntiles = (a.M + kRows - 1) / kRows;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = wg; tile < ntiles; tile += nwg) {
         const long row = (long)tile * kRows + j;
         float x[8];
         load_rows<2>(a.x, a.M, a.din, row, g, a.vec_in, x);
@@ -311,8 +316,11 @@ __device__ __forceinline__ void store_dw(float *dst, int rows, int cols, int lan
         }
 }
 
-template <int NM>
-__global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
+template <int NM, bool PAIR>
+__global__ __launch_bounds__(64) void head_bwd_kernel(VecPair<Args> ga) {
+    const int set = PAIR && (int)blockIdx.x >= ga.nwg0;
+    const Args &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x, nwg = set ? ga.nwg1 : ga.nwg0;
     __shared__ __align__(16) float tiles[6][kRows * kLd];   // two operand tiles; all six for the final column sums
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
     valid_mask<2>(a.din, g, vin);
 
     const int ntiles = (a.M + kRows - 1) / kRows;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = wg; tile < ntiles; tile += nwg) {
         const long row = (long)tile * kRows + j;
         // ---- forward again, keeping what the backward needs --------------------------------------
         float x1[8], xh0[8], rstd0 = 1.f;
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
 
     // ---- this workgroup's partial parameter gradients -------------------------------------------------
     const GradLayout gl = grad_layout(a.din, a.dmid, a.dout);
-    float *slab = a.slabs + (long)blockIdx.x * a.slab_stride;
+    float *slab = a.slabs + (long)wg * a.slab_stride;
     store_dw<NM, 2>(slab + gl.w1, a.dmid, a.din, lane, dW1);
     store_dw<2, NM>(slab + gl.w2, a.dout, a.dmid, lane, dW2);     // zeros for a shallow head
     // bias / LayerNorm-parameter gradients: the six per-lane accumulator sets go to LDS together and every
@@ -467,11 +475,20 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(Args a) {
 // out[i] (=|+=) sum over workgroups of slabs[k * stride + i]: 32 elements x 32 slab groups per workgroup,
 // so a thread sums only a handful of partials with all its loads in flight together; fixed order.
 constexpr int kRedGroups = 32;
-__global__ __launch_bounds__(32 * kRedGroups) void head_reduce_kernel(const float *slabs, long stride, int nslabs,
-                                                                      float *out, int n, int accumulate) {
+struct ReduceArgs {
+    const float *slabs; long stride; int nslabs;
+    float *out; int n, accumulate;
+};
+__global__ __launch_bounds__(32 * kRedGroups) void head_reduce_kernel(VecPair<ReduceArgs> ga) {
     __shared__ float part[kRedGroups][32];
+    const int set = (int)blockIdx.x >= ga.nwg0;
+    const ReduceArgs &a = ga.g[set];
+    const int wg = set ? blockIdx.x - ga.nwg0 : blockIdx.x;
+    const float *slabs = a.slabs;
+    const long stride = a.stride;
+    const int nslabs = a.nslabs, n = a.n;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + e;
+    const int idx = wg * 32 + e;
     const int per = (nslabs + kRedGroups - 1) / kRedGroups;
     const int c0 = grp * per, c1 = min(nslabs, c0 + per);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(32 * kRedGroups) void head_reduce_kernel(const floa
         u3 += part[g + 3][e];
     }
     const float v = (u0 + u1) + (u2 + u3);
-    out[idx] = accumulate ? out[idx] + v : v;
+    a.out[idx] = a.accumulate ? a.out[idx] + v : v;
 }
 
 int workgroups(int M) {
@@ -512,17 +529,101 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 using namespace tgru;
 
-extern "C" {
+namespace {
 
-static int head_check(int M, int din, int dmid, int dout, const void *w1, const void *c1, const void *w2) {
-    if (M <= 0 || din <= 0 || dmid <= 0 || dout <= 0) return TGRU_E_DIMS;
-    if (din > head::kIo || dout > head::kIo || dmid > head::kMid) return TGRU_E_DIMS;
-    if (!w2 && dout != dmid) return TGRU_E_DIMS;
-    if ((long long)M * 64 >= (1LL << 31)) return TGRU_E_DIMS;
-    if (!w1 || !c1) return TGRU_E_NULL;
-    if (!head::aligned16(w1) || (w2 && !head::aligned16(w2))) return TGRU_E_ALIGN;
+int head_check(const tgru_head_args &c, bool backward) {
+    if (c.M <= 0 || c.din <= 0 || c.dmid <= 0 || c.dout <= 0) return TGRU_E_DIMS;
+    if (c.din > head::kIo || c.dout > head::kIo || c.dmid > head::kMid) return TGRU_E_DIMS;
+    if (!c.w2 && c.dout != c.dmid) return TGRU_E_DIMS;
+    if ((long long)c.M * 64 >= (1LL << 31)) return TGRU_E_DIMS;
+    if (!c.w1 || !c.b1 || !c.x) return TGRU_E_NULL;
+    if ((c.ln0_w && !c.ln0_b) || (c.w2 && (!c.ln1_w || !c.ln1_b || !c.b2))) return TGRU_E_NULL;
+    if (backward ? (!c.dy || !c.dparams || !c.workspace) : !c.y) return TGRU_E_NULL;
+    if (!head::aligned16(c.w1) || (c.w2 && !head::aligned16(c.w2))) return TGRU_E_ALIGN;
     return TGRU_OK;
 }
+
+void head_fill(const tgru_head_args &c, bool backward, head::Args &a) {
+    a.x = c.x; a.g0 = c.ln0_w; a.b0 = c.ln0_b; a.w1 = c.w1; a.c1 = c.b1; a.g1 = c.ln1_w; a.b1 = c.ln1_b;
+    a.w2 = c.w2; a.c2 = c.b2; a.M = c.M; a.din = c.din; a.dmid = c.dmid; a.dout = c.dout; a.eps = c.eps;
+    if (backward) {
+        a.dy = c.dy; a.dx = c.dx;
+        a.vec_in = (c.din % 4 == 0) && head::aligned16(c.x) && (!c.dx || head::aligned16(c.dx));
+        a.vec_out = (c.dout % 4 == 0) && head::aligned16(c.dy);
+        a.slabs = c.workspace; a.slab_stride = head::grad_layout(c.din, c.dmid, c.dout).total;
+    } else {
+        a.y = c.y;
+        a.vec_in = (c.din % 4 == 0) && head::aligned16(c.x);
+        a.vec_out = (c.dout % 4 == 0) && head::aligned16(c.y);
+    }
+}
+
+template <bool BWD>
+hipError_t head_launch(const head::Args &a, const head::Args *second, hipStream_t s) {
+    VecPair<head::Args> ga{};
+    ga.g[0] = a;
+    ga.nwg0 = head::workgroups(a.M);
+    int dmid = a.dmid;
+    if (second) {
+        ga.g[1] = *second;
+        ga.nwg1 = head::workgroups(second->M);
+        if (second->dmid > dmid) dmid = second->dmid;
+    }
+    const dim3 grid(ga.nwg0 + ga.nwg1), block(64);
+    const bool wide = dmid > 32;
+#define TGRU_HEAD_LAUNCH(K)                                                                       \
+    do {                                                                                          \
+        if (wide && second) hipLaunchKernelGGL((head::K<4, true>), grid, block, 0, s, ga);        \
+        else if (wide) hipLaunchKernelGGL((head::K<4, false>), grid, block, 0, s, ga);            \
+        else if (second) hipLaunchKernelGGL((head::K<2, true>), grid, block, 0, s, ga);           \
+        else hipLaunchKernelGGL((head::K<2, false>), grid, block, 0, s, ga);                      \
+    } while (0)
+    if (BWD) TGRU_HEAD_LAUNCH(head_bwd_kernel);
+    else TGRU_HEAD_LAUNCH(head_fwd_kernel);
+#undef TGRU_HEAD_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t head_reduce_launch(const tgru_head_args &a, const tgru_head_args *second, hipStream_t s) {
+    VecPair<head::ReduceArgs> ga{};
+    const tgru_head_args *both[2] = {&a, second};
+    int nwg[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        if (!both[k]) continue;
+        const tgru_head_args &c = *both[k];
+        const int total = head::grad_layout(c.din, c.dmid, c.dout).total;
+        ga.g[k] = head::ReduceArgs{c.workspace, (long)total, head::workgroups(c.M), c.dparams, total, c.accumulate};
+        nwg[k] = (total + 31) / 32;
+    }
+    ga.nwg0 = nwg[0]; ga.nwg1 = nwg[1];
+    hipLaunchKernelGGL(head::head_reduce_kernel, dim3(nwg[0] + nwg[1]), dim3(32 * head::kRedGroups), 0, s, ga);
+    return hipGetLastError();
+}
+
+int head_forward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStream_t s) {
+    int rc = head_check(*a, false);
+    if (rc == TGRU_OK && b) rc = head_check(*b, false);
+    if (rc != TGRU_OK) return rc;
+    head::Args fa{}, fb{};
+    head_fill(*a, false, fa);
+    if (b) head_fill(*b, false, fb);
+    return head_launch<false>(fa, b ? &fb : nullptr, s) == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+}
+
+int head_backward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStream_t s) {
+    int rc = head_check(*a, true);
+    if (rc == TGRU_OK && b) rc = head_check(*b, true);
+    if (rc != TGRU_OK) return rc;
+    head::Args fa{}, fb{};
+    head_fill(*a, true, fa);
+    if (b) head_fill(*b, true, fb);
+    if (head_launch<true>(fa, b ? &fb : nullptr, s) != hipSuccess) return TGRU_E_LAUNCH;
+    return head_reduce_launch(*a, b, s) == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
 
 size_t tgru_head_grad_floats(int din, int dmid, int dout) {
     return (size_t)head::grad_layout(din, dmid, dout).total;
@@ -536,43 +637,31 @@ size_t tgru_head_backward_workspace_bytes(int M, int din, int dmid, int dout) {
 int tgru_head_forward(const float *x, float *y, int M, int din, int dmid, int dout, const float *ln0_w,
                       const float *ln0_b, const float *w1, const float *b1, const float *ln1_w,
                       const float *ln1_b, const float *w2, const float *b2, float eps, tgru_stream_t stream) {
-    int rc = head_check(M, din, dmid, dout, w1, b1, w2);
-    if (rc != TGRU_OK) return rc;
-    if (!x || !y || (ln0_w && !ln0_b) || (w2 && (!ln1_w || !ln1_b || !b2))) return TGRU_E_NULL;
-    head::Args a{};
-    a.x = x; a.y = y; a.g0 = ln0_w; a.b0 = ln0_b; a.w1 = w1; a.c1 = b1; a.g1 = ln1_w; a.b1 = ln1_b;
-    a.w2 = w2; a.c2 = b2; a.M = M; a.din = din; a.dmid = dmid; a.dout = dout; a.eps = eps;
-    a.vec_in = (din % 4 == 0) && head::aligned16(x);
-    a.vec_out = (dout % 4 == 0) && head::aligned16(y);
-    const dim3 grid(head::workgroups(M)), block(64);
-    if (dmid <= 32) hipLaunchKernelGGL(head::head_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(head::head_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+    tgru_head_args c{};
+    c.x = x; c.y = y; c.M = M; c.din = din; c.dmid = dmid; c.dout = dout; c.ln0_w = ln0_w; c.ln0_b = ln0_b;
+    c.w1 = w1; c.b1 = b1; c.ln1_w = ln1_w; c.ln1_b = ln1_b; c.w2 = w2; c.b2 = b2; c.eps = eps;
+    return head_forward_impl(&c, nullptr, (hipStream_t)stream);
 }
 
 int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int din, int dmid, int dout,
                        const float *ln0_w, const float *ln0_b, const float *w1, const float *b1,
                        const float *ln1_w, const float *ln1_b, const float *w2, const float *b2, float eps,
                        float *dparams, float *workspace, int accumulate, tgru_stream_t stream) {
-    int rc = head_check(M, din, dmid, dout, w1, b1, w2);
-    if (rc != TGRU_OK) return rc;
-    if (!x || !dy || !dparams || !workspace || (ln0_w && !ln0_b) || (w2 && (!ln1_w || !ln1_b || !b2)))
-        return TGRU_E_NULL;
-    const head::GradLayout gl = head::grad_layout(din, dmid, dout);
-    head::Args a{};
-    a.x = x; a.dy = dy; a.dx = dx; a.g0 = ln0_w; a.b0 = ln0_b; a.w1 = w1; a.c1 = b1; a.g1 = ln1_w;
-    a.b1 = ln1_b; a.w2 = w2; a.c2 = b2; a.M = M; a.din = din; a.dmid = dmid; a.dout = dout; a.eps = eps;
-    a.vec_in = (din % 4 == 0) && head::aligned16(x) && (!dx || head::aligned16(dx));
-    a.vec_out = (dout % 4 == 0) && head::aligned16(dy);
-    a.slabs = workspace; a.slab_stride = gl.total;
-    const int nwg = head::workgroups(M);
-    hipStream_t s = (hipStream_t)stream;
-    if (dmid <= 32) hipLaunchKernelGGL(head::head_bwd_kernel<2>, dim3(nwg), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(head::head_bwd_kernel<4>, dim3(nwg), dim3(64), 0, s, a);
-    if (hipGetLastError() != hipSuccess) return TGRU_E_LAUNCH;
-    hipLaunchKernelGGL(head::head_reduce_kernel, dim3((gl.total + 31) / 32), dim3(32 * head::kRedGroups), 0, s, workspace,
-                       (long)gl.total, nwg, dparams, gl.total, accumulate);
-    return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+    tgru_head_args c{};
+    c.x = x; c.dy = dy; c.dx = dx; c.M = M; c.din = din; c.dmid = dmid; c.dout = dout; c.ln0_w = ln0_w;
+    c.ln0_b = ln0_b; c.w1 = w1; c.b1 = b1; c.ln1_w = ln1_w; c.ln1_b = ln1_b; c.w2 = w2; c.b2 = b2; c.eps = eps;
+    c.dparams = dparams; c.workspace = workspace; c.accumulate = accumulate;
+    return head_backward_impl(&c, nullptr, (hipStream_t)stream);
+}
+
+int tgru_head_forward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream) {
+    if (!a || !b) return TGRU_E_NULL;
+    return head_forward_impl(a, b, (hipStream_t)stream);
+}
+
+int tgru_head_backward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream) {
+    if (!a || !b) return TGRU_E_NULL;
+    return head_backward_impl(a, b, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ._lib import check, lib
+from ._lib import HeadArgs, check, lib
 
 MAX_IO_WIDTH = 32
 MAX_MID_WIDTH = 64
@@ -114,3 +114,104 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
                                lin1.weight, lin1.bias,
                                None if ln1 is None else ln1.weight, None if ln1 is None else ln1.bias,
                                None if lin2 is None else lin2.weight, None if lin2 is None else lin2.bias)
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _split_grads(dparams, din, dmid, dout, params):
+    """Views of the flat gradient buffer in the order of `params` = (g0, b0, w1, c1, g1, b1, w2, c2)."""
+    g0, b0, w1, c1, g1, b1, w2, c2 = params
+    sizes = [("w1", dmid * din, (dmid, din), True), ("c1", dmid, (dmid,), True),
+             ("g0", din, (din,), g0 is not None), ("b0", din, (din,), b0 is not None),
+             ("g1", dmid, (dmid,), g1 is not None), ("b1", dmid, (dmid,), b1 is not None),
+             ("w2", dout * dmid, (dout, dmid), w2 is not None), ("c2", dout, (dout,), c2 is not None)]
+    out, o = {}, 0
+    for name, cnt, shape, present in sizes:
+        out[name] = dparams[o:o + cnt].view(shape) if present else None
+        o += cnt
+    return [out[k] for k in ("g0", "b0", "w1", "c1", "g1", "b1", "w2", "c2")]
+
+
+class _HeadPairFunction(torch.autograd.Function):
+    """(yA, yB) = two independent heads in one launch forward, one + one (reduce) backward.
+    Arguments: epsA, epsB, then xA, g0, b0, w1, c1, g1, b1, w2, c2 of head A and the same nine of head B."""
+
+    @staticmethod
+    def forward(ctx, eps_a, eps_b, *tensors):
+        heads, args = [], []
+        for k, eps in enumerate((eps_a, eps_b)):
+            x, *params = tensors[9 * k:9 * k + 9]
+            g0, b0, w1, c1, g1, b1, w2, c2 = params
+            din, dmid = x.shape[-1], w1.shape[0]
+            dout = dmid if w2 is None else w2.shape[0]
+            x2 = x.contiguous().view(-1, din)
+            params = [None if p is None else p.contiguous() for p in params]
+            y = torch.empty(x.shape[:-1] + (dout,), device=x.device, dtype=torch.float32)
+            heads.append(dict(x2=x2, params=params, dims=(x2.shape[0], din, dmid, dout, float(eps)), y=y))
+            args.append(HeadArgs(_addr(x2), _addr(y), None, None, x2.shape[0], din, dmid, dout,
+                                 *[_addr(p) for p in params], float(eps), None, None, 0))
+        dev = heads[0]["x2"].device
+        with torch.cuda.device(dev):
+            check(lib().tgru_head_forward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                  "tgru_head_forward_pair")
+        ctx.dims = [h["dims"] for h in heads]
+        ctx.present = [[p is not None for p in h["params"]] for h in heads]
+        saved = []
+        for h in heads:
+            saved += [h["x2"]] + [p for p in h["params"] if p is not None]
+        ctx.save_for_backward(*saved)
+        return heads[0]["y"], heads[1]["y"]
+
+    @staticmethod
+    def backward(ctx, dy_a, dy_b):
+        saved = list(ctx.saved_tensors)
+        dev = saved[0].device
+        args, results, keep = [], [], []
+        with torch.cuda.device(dev):
+            lb = lib()
+            for k, dy in enumerate((dy_a, dy_b)):
+                M, din, dmid, dout, eps = ctx.dims[k]
+                x2 = saved.pop(0)
+                params = [saved.pop(0) if pres else None for pres in ctx.present[k]]
+                dy2 = dy.contiguous().view(-1, dout)
+                dparams = torch.empty(lb.tgru_head_grad_floats(din, dmid, dout), device=dev, dtype=torch.float32)
+                ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
+                                 dtype=torch.float32)
+                dx = torch.empty_like(x2) if ctx.needs_input_grad[2 + 9 * k] else None
+                keep += [dy2, ws]
+                args.append(HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
+                                     *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), 0))
+                grads = _split_grads(dparams, din, dmid, dout, params)
+                results.append((None if dx is None else dx.view(dy.shape[:-1] + (din,)), grads))
+            check(lb.tgru_head_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                  "tgru_head_backward_pair")
+        out = [None, None]
+        for dx, grads in results:
+            out += [dx, *grads]
+        return tuple(out)
+
+
+def _flat_params(ln0, lin1, ln1, lin2):
+    return (None if ln0 is None else ln0.weight, None if ln0 is None else ln0.bias, lin1.weight, lin1.bias,
+            None if ln1 is None else ln1.weight, None if ln1 is None else ln1.bias,
+            None if lin2 is None else lin2.weight, None if lin2 is None else lin2.bias)
+
+
+def _eps_of(ln0, ln1):
+    if ln0 is not None and ln1 is not None:
+        assert ln0.eps == ln1.eps
+    return (ln0 or ln1).eps if (ln0 is not None or ln1 is not None) else 1e-5
+
+
+def head_apply_pair(x_a: torch.Tensor, spec_a, x_b: torch.Tensor, spec_b):
+    """(head_apply(x_a, *spec_a), head_apply(x_b, *spec_b)) for two independent heads, in one launch when
+    the fused kernels cover both; spec = (ln0, lin1, ln1, lin2) as for head_apply."""
+    ok = all(supported(x, spec[1], spec[3]) for x, spec in ((x_a, spec_a), (x_b, spec_b)))
+    if not ok or x_a.device != x_b.device:
+        return head_apply(x_a, *spec_a), head_apply(x_b, *spec_b)
+    for spec in (spec_a, spec_b):
+        assert (spec[2] is None) == (spec[3] is None)
+    return _HeadPairFunction.apply(_eps_of(spec_a[0], spec_a[2]), _eps_of(spec_b[0], spec_b[2]),
+                                   x_a, *_flat_params(*spec_a), x_b, *_flat_params(*spec_b))

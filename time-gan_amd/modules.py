@@ -20,15 +20,31 @@ import torch
 import torch.nn as nn
 
 from .gru import GRU, gru_pair
-from .head import head_apply
+from .head import head_apply, head_apply_pair
 
 
 class _RecurrentBlock(nn.Module):
     """Shared forward plumbing: pre (the feature MLP, if any) -> GRU over valid steps -> post (LayerNorm
     and the output layers).  Subclasses define `pre` / `post` and name their GRU in `_rnn_name`."""
 
+    def pre_spec(self):
+        """(ln0, lin1, ln1, lin2) of the stage before the GRU, or None when there is none."""
+        return None
+
+    def post_spec(self):
+        """(ln0, lin1, ln1, lin2) of the stage after the GRU."""
+        raise NotImplementedError
+
+    def _stage(self, x: torch.Tensor, spec) -> torch.Tensor:
+        if spec is None:
+            return x
+        return self._head(x, *spec)
+
     def pre(self, x: torch.Tensor) -> torch.Tensor:
-        return x
+        return self._stage(x, self.pre_spec())
+
+    def post(self, h: torch.Tensor) -> torch.Tensor:
+        return self._stage(h, self.post_spec())
 
     def forward(self, x: torch.Tensor, t) -> torch.Tensor:
         return self.post(self._run_rnn(getattr(self, self._rnn_name), self.pre(x), t))
@@ -47,15 +63,13 @@ class _RecurrentBlock(nn.Module):
                                                 padding_value=self.padding_value, total_length=self.seq_len)
         return h
 
-    def _head(self, x: torch.Tensor, ln0, lin1, mlp=None) -> torch.Tensor:
-        """[ln0] -> lin1 -> [mlp = (LayerNorm, ReLU, Linear)]: one fused kernel on the GPU path, the torch
-        modules themselves on the CPU path (`rnn_cls=torch.nn.GRU`)."""
+    def _head(self, x: torch.Tensor, ln0, lin1, ln1=None, lin2=None) -> torch.Tensor:
+        """[ln0] -> lin1 -> [ln1 -> ReLU -> lin2]: one fused kernel on the GPU path, the torch modules
+        themselves on the CPU path (`rnn_cls=torch.nn.GRU`)."""
         if x.is_cuda and isinstance(getattr(self, self._rnn_name), GRU):
-            if mlp is None:
-                return head_apply(x, ln0, lin1)
-            return head_apply(x, ln0, lin1, mlp[0], mlp[2])
+            return head_apply(x, ln0, lin1, ln1, lin2)
         h = lin1(x if ln0 is None else ln0(x))
-        return h if mlp is None else mlp[2](mlp[1](mlp[0](h)))
+        return h if lin2 is None else lin2(torch.relu(ln1(h)))
 
     @property
     def device(self):
@@ -81,11 +95,11 @@ class Embedding(_RecurrentBlock):
 
     _rnn_name = "emb_rnn"
 
-    def pre(self, x: torch.Tensor) -> torch.Tensor:
-        return self._head(x, None, self.mlp[0], self.mlp[1:])
+    def pre_spec(self):
+        return (None, self.mlp[0], self.mlp[1], self.mlp[3])
 
-    def post(self, h: torch.Tensor) -> torch.Tensor:
-        return self._head(h, self.norm, self.emb_linear)
+    def post_spec(self):
+        return (self.norm, self.emb_linear, None, None)
 
 
 class Recovery(_RecurrentBlock):
@@ -106,8 +120,8 @@ class Recovery(_RecurrentBlock):
 
     _rnn_name = "rec_rnn"
 
-    def post(self, h: torch.Tensor) -> torch.Tensor:
-        return self._head(h, self.norm, self.mlp[0], self.mlp[1:])
+    def post_spec(self):
+        return (self.norm, self.mlp[0], self.mlp[1], self.mlp[3])
 
 
 class Supervisor(_RecurrentBlock):
@@ -127,8 +141,8 @@ class Supervisor(_RecurrentBlock):
 
     _rnn_name = "sup_rnn"
 
-    def post(self, h: torch.Tensor) -> torch.Tensor:
-        return self._head(h, self.norm, self.mlp[0], self.mlp[1:])
+    def post_spec(self):
+        return (self.norm, self.mlp[0], self.mlp[1], self.mlp[3])
 
 
 class Generator(_RecurrentBlock):
@@ -150,11 +164,11 @@ class Generator(_RecurrentBlock):
 
     _rnn_name = "g_rnn"
 
-    def pre(self, z: torch.Tensor) -> torch.Tensor:
-        return self._head(z, None, self.mlp[0], self.mlp[1:])
+    def pre_spec(self):
+        return (None, self.mlp[0], self.mlp[1], self.mlp[3])
 
-    def post(self, h: torch.Tensor) -> torch.Tensor:
-        return self._head(h, self.norm, self.g_linear)
+    def post_spec(self):
+        return (self.norm, self.g_linear, None, None)
 
 
 class Discriminator(_RecurrentBlock):
@@ -173,8 +187,8 @@ class Discriminator(_RecurrentBlock):
 
     _rnn_name = "d_rnn"
 
-    def post(self, h: torch.Tensor) -> torch.Tensor:
-        return self._head(h, self.norm, self.mlp[0])
+    def post_spec(self):
+        return (self.norm, self.mlp[0], None, None)
 
 
 def forward_pair(net_a: _RecurrentBlock, x_a: torch.Tensor, t_a, net_b: _RecurrentBlock, x_b: torch.Tensor, t_b):
@@ -188,8 +202,13 @@ def forward_pair(net_a: _RecurrentBlock, x_a: torch.Tensor, t_a, net_b: _Recurre
                 and rnn_a.num_layers == rnn_b.num_layers)
     if not pairable:
         return net_a(x_a, t_a), net_b(x_b, t_b)
-    h_a, h_b = gru_pair(rnn_a, net_a.pre(x_a), t_a, rnn_b, net_b.pre(x_b), t_b)
-    return net_a.post(h_a), net_b.post(h_b)
+    pre_a, pre_b = net_a.pre_spec(), net_b.pre_spec()
+    if pre_a is not None and pre_b is not None:
+        u_a, u_b = head_apply_pair(x_a, pre_a, x_b, pre_b)
+    else:
+        u_a, u_b = net_a.pre(x_a), net_b.pre(x_b)
+    h_a, h_b = gru_pair(rnn_a, u_a, t_a, rnn_b, u_b, t_b)
+    return head_apply_pair(h_a, net_a.post_spec(), h_b, net_b.post_spec())
 
 
 def build_networks(cfg: Dict, rnn_cls=GRU) -> Dict[str, nn.Module]:
