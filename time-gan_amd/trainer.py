@@ -21,7 +21,8 @@ class _GraphedStep:
     """Runs `fn(*tensors) -> tuple of tensors` eagerly for the first `warmup` calls (they are real
     steps), then captures it once into a HIP graph and replays it: one graph launch instead of
     hundreds of kernel launches.  Inputs are copied into static buffers; outputs are static tensors.
-    A call with different shapes (a ragged last batch) runs eagerly."""
+    A call with different shapes (a ragged last batch) runs eagerly.  A tensor that IS the static buffer
+    (the trainer passes its own persistent input buffers) is not copied."""
 
     def __init__(self, fn, warmup: int = 2, capture_mode: str = "global"):
         self.fn, self.warmup, self.calls, self.capture_mode = fn, warmup, 0, capture_mode
@@ -34,13 +35,14 @@ class _GraphedStep:
             return self.fn(*tensors)
         if self.graph is None:
             self.shapes = shapes
-            self.static_in = [t.clone() for t in tensors]
+            self.static_in = list(tensors)      # the caller's buffers become the graph's inputs
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode=self.capture_mode):
                 self.static_out = self.fn(*self.static_in)
         for s, t in zip(self.static_in, tensors):
-            s.copy_(t)
+            if s is not t:
+                s.copy_(t)
         self.graph.replay()
         return self.static_out
 
@@ -67,7 +69,7 @@ class _GraphedDiscriminatorStep:
             return d_loss, stepped
         if self.g_fb is None:
             self.shapes = shapes
-            self.static_in = [x.clone(), z.clone()]
+            self.static_in = [x, z]             # the caller's buffers become the graph's inputs
             torch.cuda.synchronize()
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_mode):
@@ -75,8 +77,9 @@ class _GraphedDiscriminatorStep:
             self.g_step = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_step, capture_error_mode=self.capture_mode):
                 self.opt_step()
-        self.static_in[0].copy_(x)
-        self.static_in[1].copy_(z)
+        for s, t in zip(self.static_in, (x, z)):
+            if s is not t:
+                s.copy_(t)
         self.g_fb.replay()
         d_loss = self.static_out[0]
         stepped = bool(d_loss > self.threshold_of())
@@ -146,8 +149,42 @@ class TimeGANTrainer:
                                                   lambda: self.d_threshold, capture_mode=mode)
             for o in self.opt.values():
                 _init_adam_state(o)
+            # One Adam launch per sub-step instead of one per network: an optimiser over the parameters of
+            # both networks whose per-parameter state IS the state of the two optimisers it stands for
+            # (the same dict objects), so phases that step them separately continue the same moments.
+            self._opt2 = {k: self._merged(k.split("+"), lr, kw_opt) for k in ("emb_side+rec", "g+sup", "emb_main+rec")}
+            self._bufs = {}
 
     # -- helpers ---------------------------------------------------------------------------------
+    def _merged(self, names, lr, kw_opt):
+        params = [p for k in names for g in self.opt[k].param_groups for p in g["params"]]
+        merged = Adam(params, lr=lr, **kw_opt)
+        for k in names:
+            for p, st in self.opt[k].state.items():
+                merged.state[p] = st
+        return merged
+
+    def _step(self, *names):
+        """Adam update of the named optimisers (one merged launch in graph mode)."""
+        if self.use_graphs and "+".join(names) in self._opt2:
+            self._opt2["+".join(names)].step()
+        else:
+            for k in names:
+                self.opt[k].step()
+
+    def _input_buffer(self, name: str, like: torch.Tensor) -> torch.Tensor:
+        """Persistent device buffer that the captured graphs read their input from."""
+        buf = self._bufs.get(name)
+        if buf is None or buf.shape != like.shape:
+            buf = torch.empty_like(like)
+            self._bufs[name] = buf
+        return buf
+
+    def _staged(self, name: str, src: torch.Tensor) -> torch.Tensor:
+        buf = self._input_buffer(name, src)
+        buf.copy_(src)
+        return buf
+
     def _zero(self, *names):
         for k in names:
             self.nets[k].zero_grad()
@@ -166,8 +203,7 @@ class TimeGANTrainer:
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, self.lengths_of(x), group=self.group)
         e_loss0.backward()
         self._sync_grads("emb", "rec")
-        self.opt["emb_side"].step()
-        self.opt["rec"].step()
+        self._step("emb_side", "rec")
         return (e_loss0.detach(),)
 
     def _supervisor_core(self, x):
@@ -186,8 +222,7 @@ class TimeGANTrainer:
                                           group=self.group)
         g_loss.backward()
         self._sync_grads("g", "sup")
-        self.opt["g"].step()
-        self.opt["sup"].step()
+        self._step("g", "sup")
         return (g_loss.detach(),)
 
     def _joint_e_core(self, x):
@@ -197,8 +232,7 @@ class TimeGANTrainer:
                                                      group=self.group)
         e_loss.backward()
         self._sync_grads("emb", "rec")
-        self.opt["emb_main"].step()
-        self.opt["rec"].step()
+        self._step("emb_main", "rec")
         return (e_loss.detach(),)
 
     def _joint_d_fwd_bwd_core(self, x, z):
@@ -219,7 +253,7 @@ class TimeGANTrainer:
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
     def embedding_step(self, x: torch.Tensor, t=None) -> float:
         if t is None:
-            (loss,) = (self._g_emb if self.use_graphs else self._embedding_core)(x)
+            (loss,) = self._g_emb(self._staged("x", x)) if self.use_graphs else self._embedding_core(x)
             return float(loss)
         n = self.nets
         self._zero("emb", "rec", "sup")
@@ -233,7 +267,7 @@ class TimeGANTrainer:
     # -- phase 2: supervisor (TimeGANv1.py:662-683) -------------------------------------------------
     def supervisor_step(self, x: torch.Tensor, t=None) -> float:
         if t is None:
-            (loss,) = (self._g_sup if self.use_graphs else self._supervisor_core)(x)
+            (loss,) = self._g_sup(self._staged("x", x)) if self.use_graphs else self._supervisor_core(x)
             return float(loss)
         n = self.nets
         self._zero("emb", "sup")
@@ -253,14 +287,25 @@ class TimeGANTrainer:
         if t is not None:
             return self._joint_step_with_lengths(x, t, noise)
         noise = list(noise) if noise is not None else None
+        if self.use_graphs:
+            # the graphs read x and z from persistent buffers: x is staged once per iteration, the noise
+            # is drawn (or copied) straight into its buffer
+            x = self._staged("x", x)
+            zbuf = self._input_buffer("z", x)
+
+            def draw():
+                return zbuf.copy_(noise.pop(0)) if noise is not None else zbuf.uniform_()
+        else:
+            def draw():
+                return noise.pop(0) if noise is not None else torch.rand_like(x)
         g_losses, e_losses = [], []
         for _ in range(10):
-            z = noise.pop(0) if noise is not None else torch.rand_like(x)
+            z = draw()
             (g_loss,) = (self._g_gen if self.use_graphs else self._joint_g_core)(x, z)
             g_losses.append(g_loss.clone() if self.use_graphs else g_loss)
             (e_loss,) = (self._g_e if self.use_graphs else self._joint_e_core)(x)
             e_losses.append(e_loss.clone() if self.use_graphs else e_loss)
-        z = noise.pop(0) if noise is not None else torch.rand_like(x)
+        z = draw()
         if self.use_graphs:
             d_loss, stepped = self._g_d(x, z)
         else:
