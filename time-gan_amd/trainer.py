@@ -47,47 +47,6 @@ class _GraphedStep:
         return self.static_out
 
 
-class _GraphedDiscriminatorStep:
-    """Discriminator sub-step in graph mode: one graph holds zero_grad + forward + backward, a second
-    one the Adam update, replayed only when the loss exceeds the threshold (TimeGANv1.py:806-808).
-    Both are captured back to back so the update graph reads the gradient buffers the first one
-    writes; eager calls (warm-up, other shapes) run both halves eagerly for the same reason."""
-
-    def __init__(self, fwd_bwd, opt_step, threshold_of, warmup: int = 2, capture_mode: str = "global"):
-        self.fwd_bwd, self.opt_step, self.threshold_of = fwd_bwd, opt_step, threshold_of
-        self.warmup, self.calls, self.capture_mode = warmup, 0, capture_mode
-        self.g_fb, self.g_step, self.static_in, self.static_out, self.shapes = None, None, None, None, None
-
-    def __call__(self, x, z):
-        shapes = (tuple(x.shape), tuple(z.shape))
-        if self.calls < self.warmup or (self.shapes is not None and shapes != self.shapes):
-            self.calls += 1
-            (d_loss,) = self.fwd_bwd(x, z)
-            stepped = bool(d_loss > self.threshold_of())
-            if stepped:
-                self.opt_step()
-            return d_loss, stepped
-        if self.g_fb is None:
-            self.shapes = shapes
-            self.static_in = [x, z]             # the caller's buffers become the graph's inputs
-            torch.cuda.synchronize()
-            self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_mode):
-                self.static_out = self.fwd_bwd(*self.static_in)
-            self.g_step = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_step, capture_error_mode=self.capture_mode):
-                self.opt_step()
-        for s, t in zip(self.static_in, (x, z)):
-            if s is not t:
-                s.copy_(t)
-        self.g_fb.replay()
-        d_loss = self.static_out[0]
-        stepped = bool(d_loss > self.threshold_of())
-        if stepped:
-            self.g_step.replay()
-        return d_loss, stepped
-
-
 def _init_adam_state(opt):
     """Creates Adam's per-parameter state now instead of inside the first step(): a step captured
     into a graph must not contain the zero-initialisation of its own moment estimates."""
@@ -145,8 +104,9 @@ class TimeGANTrainer:
             self._g_sup = _GraphedStep(self._supervisor_core, capture_mode=mode)
             self._g_gen = _GraphedStep(self._joint_g_core, capture_mode=mode)
             self._g_e = _GraphedStep(self._joint_e_core, capture_mode=mode)
-            self._g_d = _GraphedDiscriminatorStep(self._joint_d_fwd_bwd_core, self._d_sync_and_step,
-                                                  lambda: self.d_threshold, capture_mode=mode)
+            self._g_d = _GraphedStep(self._joint_d_core, capture_mode=mode)
+            self._thr = torch.tensor(self.d_threshold, device=self.device)   # the threshold the D graph reads
+            self._thr_host = self.d_threshold
             for o in self.opt.values():
                 _init_adam_state(o)
             # One Adam launch per sub-step instead of one per network: an optimiser over the parameters of
@@ -235,20 +195,26 @@ class TimeGANTrainer:
         self._step("emb_main", "rec")
         return (e_loss.detach(),)
 
-    def _joint_d_fwd_bwd_core(self, x, z):
-        """Graph mode only: forward AND backward of the discriminator loss; whether the optimiser
-        steps is decided on the host afterwards (an unused backward changes nothing: the
-        gradients are zeroed before their next use, TimeGANv1.py:765-769,796-799)."""
+    def _joint_d_core(self, x, z):
+        """Graph mode: the whole discriminator sub-step with the `d_loss > threshold` decision
+        (TimeGANv1.py:805-808) taken ON THE DEVICE: forward and backward always run (an unused backward
+        changes nothing: the gradients are zeroed before their next use, :765-769,796-799) and the
+        fused Adam kernel receives `d_loss <= threshold` as its skip flag -- the flag mixed-precision
+        training uses to drop a step -- which leaves parameters, moments and step counters untouched.
+        No host synchronisation inside the iteration."""
         n = self.nets
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
                                               group=self.group)
         d_loss.backward()
-        return (d_loss.detach(),)
-
-    def _d_sync_and_step(self):
         self._sync_grads("d")
-        self.opt["d"].step()
+        skip = (d_loss.detach() <= self._thr).to(torch.float32)
+        self.opt["d"].found_inf = skip
+        try:
+            self.opt["d"].step()
+        finally:
+            del self.opt["d"].found_inf
+        return (d_loss.detach(), 1.0 - skip)
 
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
     def embedding_step(self, x: torch.Tensor, t=None) -> float:
@@ -307,7 +273,11 @@ class TimeGANTrainer:
             e_losses.append(e_loss.clone() if self.use_graphs else e_loss)
         z = draw()
         if self.use_graphs:
-            d_loss, stepped = self._g_d(x, z)
+            if float(self._thr_host) != self.d_threshold:     # the threshold was changed since the last call
+                self._thr.fill_(self.d_threshold)
+                self._thr_host = self.d_threshold
+            d_loss, stepped_flag = self._g_d(x, z)
+            d_loss, stepped = d_loss.clone(), bool(stepped_flag)
         else:
             n = self.nets
             self._zero("emb", "sup", "g", "d")
