@@ -1,0 +1,94 @@
+"""Seeded random shapes through the GRU module and the fused head against torch on the CPU: odd widths,
+single steps, single sequences, ragged lengths, initial states -- whatever kernel family the shape selects."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FWD_ATOL_SCALE, FWD_RTOL, GRAD_ATOL_SCALE, GRAD_RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    H = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 25, 31, 32, 33, 40, 48, 64, 96]))
+    In = int(rng.choice([1, 2, 5, 6, 7, 16, 24, 28, 31, 32, 33, 48]))
+    L = int(rng.integers(1, 5))
+    T = int(rng.choice([1, 2, 3, 7, 24, 33]))
+    B = int(rng.choice([1, 2, 3, 17, 64, 130, 257]))
+    return B, T, In, H, L, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGRU_FUZZ_SEEDS", "24"))))   # more seeds on demand
+def test_random_gru_shape_matches_torch(seed):
+    import timegan_amd as tg
+    rng = np.random.default_rng(1000 + seed)
+    B, T, In, H, L, ragged, with_h0, batch_first = _case(rng)
+    torch.manual_seed(seed)
+    ref = torch.nn.GRU(In, H, num_layers=L, batch_first=batch_first)
+    ours = tg.GRU(In, H, num_layers=L, batch_first=batch_first).to("cuda:0")
+    ours.load_state_dict(ref.state_dict())
+    x = torch.randn((B, T, In) if batch_first else (T, B, In))
+    h0 = torch.randn(L, B, H) if with_h0 else None
+    lens = sorted((int(v) for v in rng.integers(1, T + 1, B)), reverse=True) if ragged else [T] * B
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=batch_first, enforce_sorted=True)
+    yp, hn_r = ref(packed, h0)
+    y_r, _ = torch.nn.utils.rnn.pad_packed_sequence(yp, batch_first=batch_first, total_length=T)
+    wy, wh = torch.randn(y_r.shape), torch.randn(hn_r.shape)
+    ((y_r * wy).sum() + (hn_r * wh).sum()).backward()
+
+    xo = x.clone().to("cuda:0").requires_grad_(True)
+    y_o, hn_o = ours(xo, None if h0 is None else h0.to("cuda:0"), lengths=lens)
+    ((y_o * wy.to("cuda:0")).sum() + (hn_o * wh.to("cuda:0")).sum()).backward()
+    tag = f"B{B} T{T} In{In} H{H} L{L} ragged{ragged} h0{with_h0} bf{batch_first}"
+    assert_close(y_o.detach().cpu().numpy(), y_r.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y " + tag)
+    assert_close(hn_o.detach().cpu().numpy(), hn_r.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "h_n " + tag)
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx " + tag)
+    for (name, p), q in zip(ref.named_parameters(), ours.parameters()):
+        assert_close(q.grad.cpu().numpy(), p.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{name} {tag}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGRU_FUZZ_SEEDS", "24"))))
+def test_random_head_shape_matches_torch(seed):
+    import copy
+    import torch.nn as nn
+    from timegan_amd.head import head_apply, supported
+    rng = np.random.default_rng(5000 + seed)
+    deep = bool(rng.integers(0, 2))
+    ln0 = bool(rng.integers(0, 2))
+    # a LayerNorm over fewer than 8 features is ill-conditioned (rows of near-zero variance amplify rounding
+    # by 1/sqrt(eps) in any implementation), so normalised widths start at 8; the others at 1
+    din = int(rng.integers(8 if ln0 else 1, 33))
+    dmid = int(rng.integers(8, 65)) if deep else int(rng.integers(1, 33))
+    dout = int(rng.integers(1, 33)) if deep else dmid
+    M = int(rng.choice([1, 2, 15, 16, 17, 100, 513, 3072]))
+    want_dx = bool(rng.integers(0, 2))
+    torch.manual_seed(seed)
+    ref = {"ln0": nn.LayerNorm(din) if ln0 else None, "lin1": nn.Linear(din, dmid),
+           "ln1": nn.LayerNorm(dmid) if deep else None, "lin2": nn.Linear(dmid, dout) if deep else None}
+    for k in ("ln0", "ln1"):
+        if ref[k] is not None:
+            with torch.no_grad():
+                ref[k].weight.uniform_(0.5, 1.5)
+                ref[k].bias.uniform_(-0.5, 0.5)
+    ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
+    x, dy = torch.randn(M, din), torch.randn(M, dout)
+    xr = x.clone().requires_grad_(want_dx)
+    h = ref["lin1"](xr if ref["ln0"] is None else ref["ln0"](xr))
+    y_r = h if not deep else ref["lin2"](torch.relu(ref["ln1"](h)))
+    y_r.backward(dy)
+    xo = x.clone().to("cuda:0").requires_grad_(want_dx)
+    assert supported(xo, ours["lin1"], ours["lin2"])
+    y_o = head_apply(xo, ours["ln0"], ours["lin1"], ours["ln1"], ours["lin2"])
+    y_o.backward(dy.to("cuda:0"))
+    tag = f"M{M} {din}->{dmid}->{dout} ln0{ln0} deep{deep}"
+    assert_close(y_o.detach().cpu().numpy(), y_r.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y " + tag)
+    if want_dx:
+        assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx " + tag)
+    for k in ref:
+        if ref[k] is None:
+            continue
+        for (name, p), q in zip(ref[k].named_parameters(), ours[k].parameters()):
+            assert_close(q.grad.cpu().numpy(), p.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{k}.{name} {tag}")
