@@ -209,6 +209,29 @@ int tgru_head_forward_pair(const tgru_head_args *a, const tgru_head_args *b, tgr
 int tgru_head_backward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream);
 
 /*
+ * Deferred reductions.  Every backward kernel of the small-stack path (and of the heads) leaves one
+ * partial parameter-gradient vector per workgroup in `workspace`, and a short second kernel sums them.
+ * With accumulate == TGRU_DEFER_REDUCE that second kernel is NOT launched: the caller asks
+ * tgru_backward_reduce_jobs / tgru_head_reduce_jobs for the reductions that are still owed (flat jobs
+ * dst[i] = sum_{k < count} src[k * stride + i], i < n), gathers the jobs of as many calls as it likes
+ * and runs them in one launch with tgru_reduce_jobs -- before anything reads the gradients and while
+ * the workspaces are still alive.  Calls that do not run on that path ignore the flag (their
+ * gradients are complete on return) and report zero jobs.  No reference counterpart.
+ */
+#define TGRU_DEFER_REDUCE 2
+#define TGRU_MAX_REDUCE_JOBS 96      /* jobs per launch; tgru_reduce_jobs splits longer lists */
+typedef struct tgru_reduce_job {
+    const float *src;
+    int64_t stride;
+    int32_t count, n;
+    float *dst;
+} tgru_reduce_job;
+/* both return the number of jobs written (0: nothing deferred) or a negative TGRU_E_* code */
+int tgru_backward_reduce_jobs(const tgru_backward_args *a, tgru_reduce_job *jobs, int max_jobs);
+int tgru_head_reduce_jobs(const tgru_head_args *a, tgru_reduce_job *jobs, int max_jobs);
+int tgru_reduce_jobs(const tgru_reduce_job *jobs, int n_jobs, tgru_stream_t stream);
+
+/*
  * The loss expressions of the three training phases, fused (no reference FFI; they replace the
  * torch compositions at outdated_files/TimeGANv1.py:410-553):
  *   TGRU_LOSS_EMBED_SIDE     in = {x_tilde, x}                    out[0] = 10 sqrt(mse)            (:420-421)

@@ -42,6 +42,15 @@ class HeadArgs(ctypes.Structure):
                [("eps", ctypes.c_float), ("dparams", _vp), ("workspace", _vp), ("accumulate", _i)]
 
 
+class ReduceJob(ctypes.Structure):
+    """tgru_reduce_job of include/tgru.h."""
+    _fields_ = [("src", _vp), ("stride", ctypes.c_int64), ("count", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("dst", _vp)]
+
+
+DEFER_REDUCE = 2          # TGRU_DEFER_REDUCE
+MAX_JOBS_PER_CALL = 32    # upper bound of jobs one backward call can owe (5 per layer, at most 4 layers on that path)
+
 # name -> (restype, argtypes); mirrors include/tgru.h one to one
 SIGNATURES = {
     "tgru_version": (_i, []),
@@ -60,6 +69,9 @@ SIGNATURES = {
     "tgru_head_backward": (_i, [_vp] * 3 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp, _vp, _i, _vp]),
     "tgru_head_forward_pair": (_i, [ctypes.POINTER(HeadArgs)] * 2 + [_vp]),
     "tgru_head_backward_pair": (_i, [ctypes.POINTER(HeadArgs)] * 2 + [_vp]),
+    "tgru_backward_reduce_jobs": (_i, [ctypes.POINTER(BackwardArgs), ctypes.POINTER(ReduceJob), _i]),
+    "tgru_head_reduce_jobs": (_i, [ctypes.POINTER(HeadArgs), ctypes.POINTER(ReduceJob), _i]),
+    "tgru_reduce_jobs": (_i, [ctypes.POINTER(ReduceJob), _i, _vp]),
     "tgru_loss_layout": (_i, [_i] * 3 + [ctypes.POINTER(ctypes.c_int64)]),
     "tgru_loss_partial": (_i, [_i, _i, _vp] + [_i] * 4 + [_vp, _vp]),
     "tgru_loss_final": (_i, [_i] * 5 + [ctypes.c_float, _vp, _vp]),

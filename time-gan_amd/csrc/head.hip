@@ -618,7 +618,13 @@ int head_backward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStre
     head_fill(*a, true, fa);
     if (b) head_fill(*b, true, fb);
     if (head_launch<true>(fa, b ? &fb : nullptr, s) != hipSuccess) return TGRU_E_LAUNCH;
-    return head_reduce_launch(*a, b, s) == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+    // reductions that are not deferred to a later tgru_reduce_jobs launch
+    const tgru_head_args *now[2] = {nullptr, nullptr};
+    int n = 0;
+    if (a->accumulate != TGRU_DEFER_REDUCE) now[n++] = a;
+    if (b && b->accumulate != TGRU_DEFER_REDUCE) now[n++] = b;
+    if (n == 0) return TGRU_OK;
+    return head_reduce_launch(*now[0], now[1], s) == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
 
 }  // namespace
@@ -652,6 +658,17 @@ int tgru_head_backward(const float *x, const float *dy, float *dx, int M, int di
     c.ln0_b = ln0_b; c.w1 = w1; c.b1 = b1; c.ln1_w = ln1_w; c.ln1_b = ln1_b; c.w2 = w2; c.b2 = b2; c.eps = eps;
     c.dparams = dparams; c.workspace = workspace; c.accumulate = accumulate;
     return head_backward_impl(&c, nullptr, (hipStream_t)stream);
+}
+
+int tgru_head_reduce_jobs(const tgru_head_args *c, tgru_reduce_job *jobs, int max_jobs) {
+    if (!c || !jobs) return TGRU_E_NULL;
+    const int rc = head_check(*c, true);
+    if (rc != TGRU_OK) return rc;
+    if (c->accumulate != TGRU_DEFER_REDUCE) return 0;
+    if (max_jobs < 1) return TGRU_E_DIMS;
+    const int total = head::grad_layout(c->din, c->dmid, c->dout).total;
+    jobs[0] = tgru_reduce_job{c->workspace, (int64_t)total, head::workgroups(c->M), total, c->dparams};
+    return 1;
 }
 
 int tgru_head_forward_pair(const tgru_head_args *a, const tgru_head_args *b, tgru_stream_t stream) {

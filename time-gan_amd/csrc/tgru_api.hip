@@ -350,7 +350,7 @@ static void fill_small_bwd(const tgru_backward_args &c, bool vec, SmallBwdArgs &
     b.dx_ext = c.dx; b.dxmap = ext_map(d, c.toff); b.In = c.In; b.dh0 = c.dh0; b.db_part = dbp;
     b.lengths = c.lengths; b.B = c.B; b.T = c.T; b.H = c.H; b.L = c.L;
     g.x = c.x; g.xmap = ext_map(d, c.toff); g.In = c.In; g.h0 = c.h0; g.db_part = dbp;
-    g.B = c.B; g.T = c.T; g.H = c.H; g.L = c.L; g.accumulate = c.accumulate;
+    g.B = c.B; g.T = c.T; g.H = c.H; g.L = c.L; g.accumulate = c.accumulate == TGRU_DEFER_REDUCE ? 0 : c.accumulate;
     g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(c.In, c.H, c.L);
     if (vec) {
         b.x = c.x; b.xmap = ext_map(d, c.toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
@@ -370,6 +370,8 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
                                dx, dh0, dw_ih, dw_hh, db_ih, db_hh, B, T, In, H, L, layout, accumulate};
     int rc = check_backward(c);
     if (rc != TGRU_OK) return rc;
+    const bool defer = accumulate == TGRU_DEFER_REDUCE;   // honoured by the one-sequence-per-workgroup path only
+    if (defer) accumulate = 0;
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     const BwdWs w = bwd_ws(d);
@@ -390,7 +392,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         if (vec) {
             // the backward kernel accumulates the weight gradients itself: one partial per workgroup
             TGRU_HIP(launch_gru_vec_bwd(b, nullptr, s));
-            TGRU_HIP(launch_gru_small_wgrad_reduce(g, nullptr, s));
+            if (!defer) TGRU_HIP(launch_gru_small_wgrad_reduce(g, nullptr, s));
             return TGRU_OK;
         }
         TGRU_HIP(launch_gru_small_bwd(b, s));
@@ -503,8 +505,38 @@ int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b,
     fill_small_bwd(*b, true, bb, gb);
     hipStream_t s = (hipStream_t)stream;
     TGRU_HIP(launch_gru_vec_bwd(ba, &bb, s));
-    TGRU_HIP(launch_gru_small_wgrad_reduce(ga, &gb, s));
+    const bool da = a->accumulate == TGRU_DEFER_REDUCE, db = b->accumulate == TGRU_DEFER_REDUCE;
+    if (!da && !db) TGRU_HIP(launch_gru_small_wgrad_reduce(ga, &gb, s));
+    else if (!da) TGRU_HIP(launch_gru_small_wgrad_reduce(ga, nullptr, s));
+    else if (!db) TGRU_HIP(launch_gru_small_wgrad_reduce(gb, nullptr, s));
     return TGRU_OK;
+}
+
+int tgru_backward_reduce_jobs(const tgru_backward_args *c, tgru_reduce_job *jobs, int max_jobs) {
+    if (!c || !jobs) return TGRU_E_NULL;
+    int rc = check_backward(*c);
+    if (rc != TGRU_OK) return rc;
+    if (c->accumulate != TGRU_DEFER_REDUCE || !use_vec(c->B, c->T, c->In, c->H, c->L, c->layout)) return 0;
+    if (max_jobs < 5 * c->L) return TGRU_E_DIMS;
+    SmallBwdArgs b{};
+    SmallWgradArgs g{};
+    fill_small_bwd(*c, true, b, g);
+    const int H = c->H, L = c->L;
+    int n = 0;
+    long off = 0;
+    for (int l = 0; l < L; ++l) {
+        const int n_ih = 3 * H * (l == 0 ? c->In : H), n_hh = 3 * H * H;
+        jobs[n++] = tgru_reduce_job{g.slabs + off, g.slab_stride, g.nchunks, n_ih, g.dw_ih[l]};
+        jobs[n++] = tgru_reduce_job{g.slabs + off + n_ih, g.slab_stride, g.nchunks, n_hh, g.dw_hh[l]};
+        off += n_ih + n_hh;
+        // bias partials: one row (r | z | n | n*r) per workgroup and layer
+        const float *bp = g.db_part + (long)l * 4 * H;
+        const int64_t bs = (int64_t)L * 4 * H;
+        jobs[n++] = tgru_reduce_job{bp, bs, g.nblk, 3 * H, g.db_ih[l]};
+        jobs[n++] = tgru_reduce_job{bp, bs, g.nblk, 2 * H, g.db_hh[l]};
+        jobs[n++] = tgru_reduce_job{bp + 3 * H, bs, g.nblk, H, g.db_hh[l] + 2 * H};
+    }
+    return n;
 }
 
 }  // extern "C"

@@ -9,12 +9,29 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 from ._lib import BackwardArgs, ForwardArgs, LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib
 
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _addr(t) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _alloc_grads(weights: Sequence[torch.Tensor]):
+    """One flat buffer for the gradients of `weights` and a view of it per weight.  Autograd receives the
+    views (no one else references them, so AccumulateGrad adopts them without copying -- a copy taken
+    before a deferred reduction has run would copy nothing useful); whoever must keep the memory alive
+    holds the flat buffer."""
+    flat = torch.empty(sum(w.numel() for w in weights), device=weights[0].device, dtype=torch.float32)
+    views, o = [], 0
+    for w in weights:
+        views.append(flat[o:o + w.numel()].view(w.shape))
+        o += w.numel()
+    return flat, views
 
 
 def _ptr_array(ts: Sequence[torch.Tensor]):
@@ -106,20 +123,23 @@ class _GRUFunction(torch.autograd.Function):
                              dtype=torch.float32)
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dh0 = torch.empty_like(h0) if (ctx.has_h0 and ctx.needs_input_grad[1]) else None
-            grads = [torch.empty_like(w) for w in weights]
-            gw_ih, gw_hh, gb_ih, gb_hh = _split_weights(grads, L)
-            rc = lb.tgru_backward(_ptr(dy), _ptr(dh_n), _ptr(x), _ptr(h0), _ptr(y),
-                                  _ptr(lengths), _ptr(toff),
-                                  _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
-                                  _ptr(reserve), _ptr(ws), _ptr(dx), _ptr(dh0),
-                                  _ptr_array(gw_ih), _ptr_array(gw_hh), _ptr_array(gb_ih), _ptr_array(gb_hh),
-                                  B, T, In, H, L, layout, 0, _stream(dev))
+            flat, grads = _alloc_grads(weights)
+            arrays = [_ptr_array(g) for g in _split_weights(weights, L)] + \
+                     [_ptr_array(g) for g in _split_weights(grads, L)]
+            cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays]
+            queue = deferred.active()
+            defer = queue is not None and queue.may_defer(weights)
+            args = BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths), _addr(toff),
+                                *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0), *cast[4:],
+                                B, T, In, H, L, layout, _lib.DEFER_REDUCE if defer else 0)
+            rc = lb.tgru_backward(args.dy, args.dh_n, args.x, args.h0, args.y, args.lengths, args.toff,
+                                  args.w_ih, args.w_hh, args.b_ih, args.b_hh, args.reserve, args.workspace,
+                                  args.dx, args.dh0, args.dw_ih, args.dw_hh, args.db_ih, args.db_hh,
+                                  B, T, In, H, L, layout, args.accumulate, _stream(dev))
             check(rc, "tgru_backward")
+            if defer:
+                queue.add(lb.tgru_backward_reduce_jobs, args, [ws, arrays, flat], weights, dev)
         return (dx, dh0, None, None, None, None, None, *grads)
-
-
-def _addr(t) -> Optional[int]:
-    return None if t is None else t.data_ptr()
 
 
 class _GRUPairFunction(torch.autograd.Function):
@@ -177,6 +197,10 @@ class _GRUPairFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         dev = saved[0].device
         keep, args, results = [], [], []
+        all_w = [w for k in range(2) for w in saved[k * (6 + nw) + 6:(k + 1) * (6 + nw)]]
+        queue = deferred.active()
+        defer = queue is not None and queue.may_defer(all_w)
+        flag = _lib.DEFER_REDUCE if defer else 0
         with torch.cuda.device(dev):
             lb = lib()
             for k in range(2):
@@ -190,17 +214,20 @@ class _GRUPairFunction(torch.autograd.Function):
                                  dtype=torch.float32)
                 dx = torch.empty_like(x) if ctx.needs_input_grad[base] else None
                 dh0 = torch.empty_like(h0) if (has_h0 and ctx.needs_input_grad[base + 1]) else None
-                grads = [torch.empty_like(w) for w in weights]
+                flat, grads = _alloc_grads(weights)
                 arrays = [_ptr_array(g) for g in _split_weights(weights, L)] + \
                          [_ptr_array(g) for g in _split_weights(grads, L)]
-                keep += arrays + [ws, dy, dh_n]
+                keep += arrays + [ws, dy, dh_n, flat]
                 cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays]
                 args.append(BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths),
                                          _addr(toff), *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0),
-                                         *cast[4:], B, T, In, H, L, layout, 0))
+                                         *cast[4:], B, T, In, H, L, layout, flag))
                 results.append((dx, dh0, grads))
             check(lb.tgru_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
                   "tgru_backward_pair")
+            if defer:
+                for a in args:
+                    queue.add(lb.tgru_backward_reduce_jobs, a, keep, all_w, dev)
         out = [None]
         for dx, dh0, grads in results:
             out += [dx, dh0, None, None, *grads]

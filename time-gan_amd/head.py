@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import _lib, deferred
 from ._lib import HeadArgs, check, lib
 
 MAX_IO_WIDTH = 32
@@ -21,6 +22,10 @@ MAX_MID_WIDTH = 64
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
 
 
 def _stream(device) -> ctypes.c_void_p:
@@ -61,9 +66,17 @@ class _HeadFunction(torch.autograd.Function):
             ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
                              dtype=torch.float32)
             dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+            live = [p for p in params if p is not None]
+            queue = deferred.active()
+            defer = queue is not None and queue.may_defer(live)
+            flag = _lib.DEFER_REDUCE if defer else 0
             check(lb.tgru_head_backward(_ptr(x2), _ptr(dy2), _ptr(dx), M, din, dmid, dout,
-                                        *[_ptr(p) for p in params], eps, _ptr(dparams), _ptr(ws), 0,
+                                        *[_ptr(p) for p in params], eps, _ptr(dparams), _ptr(ws), flag,
                                         _stream(dev)), "tgru_head_backward")
+            if defer:
+                args = HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
+                                *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), flag)
+                queue.add(lb.tgru_head_reduce_jobs, args, [ws, dparams, dy2], live, dev)
         o = 0
 
         def take(cnt, shape, present):
@@ -116,10 +129,6 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
                                None if lin2 is None else lin2.weight, None if lin2 is None else lin2.bias)
 
 
-def _addr(t):
-    return None if t is None else t.data_ptr()
-
-
 def _split_grads(dparams, din, dmid, dout, params):
     """Views of the flat gradient buffer in the order of `params` = (g0, b0, w1, c1, g1, b1, w2, c2)."""
     g0, b0, w1, c1, g1, b1, w2, c2 = params
@@ -168,25 +177,36 @@ class _HeadPairFunction(torch.autograd.Function):
     def backward(ctx, dy_a, dy_b):
         saved = list(ctx.saved_tensors)
         dev = saved[0].device
-        args, results, keep = [], [], []
+        args, results, keep, live = [], [], [], []
+        queue = deferred.active()
         with torch.cuda.device(dev):
             lb = lib()
-            for k, dy in enumerate((dy_a, dy_b)):
-                M, din, dmid, dout, eps = ctx.dims[k]
+            heads = []
+            for k in range(2):
                 x2 = saved.pop(0)
                 params = [saved.pop(0) if pres else None for pres in ctx.present[k]]
+                heads.append((x2, params))
+                live += [p for p in params if p is not None]
+            defer = queue is not None and queue.may_defer(live)
+            flag = _lib.DEFER_REDUCE if defer else 0
+            for k, dy in enumerate((dy_a, dy_b)):
+                M, din, dmid, dout, eps = ctx.dims[k]
+                x2, params = heads[k]
                 dy2 = dy.contiguous().view(-1, dout)
                 dparams = torch.empty(lb.tgru_head_grad_floats(din, dmid, dout), device=dev, dtype=torch.float32)
                 ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
                                  dtype=torch.float32)
                 dx = torch.empty_like(x2) if ctx.needs_input_grad[2 + 9 * k] else None
-                keep += [dy2, ws]
+                keep += [dy2, ws, dparams]
                 args.append(HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
-                                     *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), 0))
+                                     *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), flag))
                 grads = _split_grads(dparams, din, dmid, dout, params)
                 results.append((None if dx is None else dx.view(dy.shape[:-1] + (din,)), grads))
             check(lb.tgru_head_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
                   "tgru_head_backward_pair")
+            if defer:
+                for a in args:
+                    queue.add(lb.tgru_head_reduce_jobs, a, keep, live, dev)
         out = [None, None]
         for dx, grads in results:
             out += [dx, *grads]

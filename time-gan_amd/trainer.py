@@ -11,6 +11,7 @@ import torch
 from torch.optim import Adam
 
 from . import losses
+from .deferred import deferred_reductions
 from .modules import build_networks
 import torch.distributed as dist
 
@@ -161,7 +162,8 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, self.lengths_of(x), group=self.group)
-        e_loss0.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            e_loss0.backward()
         self._sync_grads("emb", "rec")
         self._step("emb_side", "rec")
         return (e_loss0.detach(),)
@@ -170,7 +172,8 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "sup")
         s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
-        s_loss.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            s_loss.backward()
         self._sync_grads("sup")
         self.opt["sup"].step()
         return (s_loss.detach(),)
@@ -180,7 +183,8 @@ class TimeGANTrainer:
         self._zero("emb", "rec", "sup", "g", "d")
         g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
                                           group=self.group)
-        g_loss.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            g_loss.backward()
         self._sync_grads("g", "sup")
         self._step("g", "sup")
         return (g_loss.detach(),)
@@ -190,7 +194,8 @@ class TimeGANTrainer:
         self._zero("emb", "rec", "sup")
         e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
                                                      group=self.group)
-        e_loss.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            e_loss.backward()
         self._sync_grads("emb", "rec")
         self._step("emb_main", "rec")
         return (e_loss.detach(),)
@@ -206,7 +211,8 @@ class TimeGANTrainer:
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
                                               group=self.group)
-        d_loss.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            d_loss.backward()
         self._sync_grads("d")
         skip = (d_loss.detach() <= self._thr).to(torch.float32)
         self.opt["d"].found_inf = skip
@@ -224,7 +230,8 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, t, group=self.group)
-        e_loss0.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            e_loss0.backward()
         self._sync_grads("emb", "rec")
         self.opt["emb_side"].step()
         self.opt["rec"].step()
@@ -238,7 +245,8 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "sup")
         s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
-        s_loss.backward()
+        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            s_loss.backward()
         self._sync_grads("sup")
         self.opt["sup"].step()
         return float(s_loss.detach())
@@ -285,7 +293,8 @@ class TimeGANTrainer:
                                                   group=self.group)
             stepped = bool(d_loss > self.d_threshold)
             if stepped:
-                d_loss.backward()
+                with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+                    d_loss.backward()
                 self._sync_grads("d")
                 self.opt["d"].step()
         return {"g_loss": [float(v) for v in torch.stack(g_losses).tolist()],
@@ -301,14 +310,16 @@ class TimeGANTrainer:
             self._zero("emb", "rec", "sup", "g", "d")
             g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
                                               group=self.group)
-            g_loss.backward()
+            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+                g_loss.backward()
             out["g_loss"].append(float(g_loss.detach()))
             self._sync_grads("g", "sup")
             self.opt["g"].step()
             self.opt["sup"].step()
             self._zero("emb", "rec", "sup")
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
-            e_loss.backward()
+            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+                e_loss.backward()
             out["e_loss"].append(float(e_loss.detach()))
             self._sync_grads("emb", "rec")
             self.opt["emb_main"].step()
@@ -318,7 +329,8 @@ class TimeGANTrainer:
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z, group=self.group)
         stepped = bool(d_loss > self.d_threshold)
         if stepped:
-            d_loss.backward()
+            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+                d_loss.backward()
             self._sync_grads("d")
             self.opt["d"].step()
         out["d_loss"] = float(d_loss.detach())
