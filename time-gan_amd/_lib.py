@@ -79,6 +79,26 @@ SIGNATURES = {
 }
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(device):
+    """Context in which `device` is the current GPU.  The library launches on the current device; when it
+    already is `device` (the usual case) nothing is switched -- torch.cuda.device() costs ~10 us a use."""
+    import torch
+    if torch.cuda.current_device() == device.index:
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 class TgruError(RuntimeError):
     pass
 

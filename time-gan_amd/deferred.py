@@ -17,7 +17,7 @@ from contextlib import contextmanager
 
 import torch
 
-from ._lib import MAX_JOBS_PER_CALL, ReduceJob, check, lib
+from ._lib import MAX_JOBS_PER_CALL, ReduceJob, check, lib, on_device
 
 _active = None
 
@@ -64,7 +64,7 @@ class _Queue:
 
     def flush(self):
         if self.count:
-            with torch.cuda.device(self.device):
+            with on_device(self.device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
                 check(lib().tgru_reduce_jobs(self.jobs, self.count, stream), "tgru_reduce_jobs")
         self.count, self.keep, self.pending = 0, [], set()

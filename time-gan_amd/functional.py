@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, deferred
-from ._lib import BackwardArgs, ForwardArgs, LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib
+from ._lib import BackwardArgs, ForwardArgs, LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF, check, lib, on_device
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -86,7 +86,7 @@ class _GRUFunction(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
         dev = x.device
         need_grad = any(ctx.needs_input_grad)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             y = torch.empty(x.shape[:-1] + (H,), device=dev, dtype=torch.float32)
             if layout == LAYOUT_PACKED:
@@ -117,7 +117,7 @@ class _GRUFunction(torch.autograd.Function):
         dev = x.device
         dy = torch.zeros_like(y) if dy is None else dy.contiguous()   # only h_n was used
         dh_n = None if dh_n is None else dh_n.contiguous()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             ws = torch.empty(lb.tgru_backward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
                              dtype=torch.float32)
@@ -163,7 +163,7 @@ class _GRUPairFunction(torch.autograd.Function):
         dev = calls[0]["x"].device
         need_grad = any(ctx.needs_input_grad)
         keep, args = [], []
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             for c in calls:
                 B, T, In, H, L, layout = (c[k] for k in ("B", "T", "In", "H", "L", "layout"))
@@ -201,7 +201,7 @@ class _GRUPairFunction(torch.autograd.Function):
         queue = deferred.active()
         defer = queue is not None and queue.may_defer(all_w)
         flag = _lib.DEFER_REDUCE if defer else 0
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             for k in range(2):
                 x, h0, y, lengths, toff, reserve, *weights = saved[k * (6 + nw):(k + 1) * (6 + nw)]
@@ -269,7 +269,7 @@ def gru_forward_backward_raw(x, weights, B, T, layout, dy, h0=None, dh_n=None, l
     In, H, L = _dims(x, layout, B, T, weights)
     w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
     dev = x.device
-    with torch.cuda.device(dev):
+    with on_device(dev):
         lb = lib()
         y = torch.empty(x.shape[:-1] + (H,), device=dev, dtype=torch.float32)
         h_n = torch.empty((L, B, H), device=dev, dtype=torch.float32)
@@ -305,7 +305,7 @@ def input_projection(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     N = w.shape[0]
     assert w.shape[1] == K
     out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    with torch.cuda.device(a.device):
+    with on_device(a.device):
         check(lib().tgru_input_projection(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K,
                                           _stream(a.device)), "tgru_input_projection")
     return out

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, deferred
-from ._lib import HeadArgs, check, lib
+from ._lib import HeadArgs, check, lib, on_device
 
 MAX_IO_WIDTH = 32
 MAX_MID_WIDTH = 64
@@ -42,7 +42,7 @@ class _HeadFunction(torch.autograd.Function):
         M = x2.shape[0]
         params = [None if p is None else p.contiguous() for p in (g0, b0, w1, c1, g1, b1, w2, c2)]
         y = torch.empty(x.shape[:-1] + (dout,), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             check(lib().tgru_head_forward(_ptr(x2), _ptr(y), M, din, dmid, dout, *[_ptr(p) for p in params],
                                           float(eps), _stream(x.device)), "tgru_head_forward")
         ctx.dims = (M, din, dmid, dout, float(eps))
@@ -59,7 +59,7 @@ class _HeadFunction(torch.autograd.Function):
         g0, b0, w1, c1, g1, b1, w2, c2 = params
         dev = x2.device
         dy2 = dy.contiguous().view(-1, dout)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             n = lb.tgru_head_grad_floats(din, dmid, dout)
             dparams = torch.empty(n, device=dev, dtype=torch.float32)
@@ -162,7 +162,7 @@ class _HeadPairFunction(torch.autograd.Function):
             args.append(HeadArgs(_addr(x2), _addr(y), None, None, x2.shape[0], din, dmid, dout,
                                  *[_addr(p) for p in params], float(eps), None, None, 0))
         dev = heads[0]["x2"].device
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib().tgru_head_forward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
                   "tgru_head_forward_pair")
         ctx.dims = [h["dims"] for h in heads]
@@ -179,7 +179,7 @@ class _HeadPairFunction(torch.autograd.Function):
         dev = saved[0].device
         args, results, keep, live = [], [], [], []
         queue = deferred.active()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             heads = []
             for k in range(2):

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device
 from .parallel import multi_rank
 
 EMBED_SIDE, SUPERVISOR, EMBED_MAIN, DISCRIMINATOR, GENERATOR = range(5)
@@ -47,7 +47,7 @@ class _LossFunction(torch.autograd.Function):
         tensors = tuple(t.contiguous() for t in tensors)
         dev = tensors[0].device
         ctx.set_materialize_grads(False)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             lb = lib()
             lay = (ctypes.c_int64 * 4)()
             check(lb.tgru_loss_layout(kind, T, F, lay), "tgru_loss_layout")
@@ -77,7 +77,7 @@ class _LossFunction(torch.autograd.Function):
         dev = buf.device
         grads = [torch.empty_like(t) if ctx.needs_input_grad[4 + i] else None for i, t in enumerate(tensors)]
         ups = [None if g is None else g.contiguous() for g in (g0, g1, g2)]
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib().tgru_loss_backward(kind, _ptrs(tensors, 6), _ptrs(grads, 6), _ptrs(ups, 3), B, T, H, F,
                                            gamma, ctypes.c_void_p(buf.data_ptr()), _stream(dev)),
                   "tgru_loss_backward")

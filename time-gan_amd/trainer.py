@@ -76,6 +76,7 @@ class TimeGANTrainer:
         for k in self.nets:
             self.nets[k] = self.nets[k].to(self.device)
         self.group = group
+        self._params = {}
         broadcast_parameters(self.nets.values(), group=group)
         lr = float(cfg["system"]["lr"])
         n = self.nets
@@ -147,8 +148,14 @@ class TimeGANTrainer:
         return buf
 
     def _zero(self, *names):
+        """zero_grad() of the named networks (gradients set to None, torch's default), from cached
+        parameter lists: Module.zero_grad() walks the module tree on every call."""
         for k in names:
-            self.nets[k].zero_grad()
+            params = self._params.get(k)
+            if params is None:
+                params = self._params[k] = list(self.nets[k].parameters())
+            for p in params:
+                p.grad = None
 
     def _sync_grads(self, *names):
         all_reduce_grads([self.nets[k] for k in names], group=self.group)
