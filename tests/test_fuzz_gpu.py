@@ -92,3 +92,33 @@ def test_random_head_shape_matches_torch(seed):
             continue
         for (name, p), q in zip(ref[k].named_parameters(), ours[k].parameters()):
             assert_close(q.grad.cpu().numpy(), p.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{k}.{name} {tag}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGRU_FUZZ_SEEDS", "24"))))
+def test_random_loss_shape_matches_torch(seed):
+    """The fused loss ops against the torch composition on random shapes (test_loss_gpu.py holds the helpers)."""
+    from test_loss_gpu import FWD_RTOL as LF, GRAD_RTOL as LG, _close, _operands, _torch_loss
+    from timegan_amd import loss_ops as lo
+    rng = np.random.default_rng(9000 + seed)
+    kind = int(rng.integers(0, 5))
+    B = int(rng.choice([1, 2, 3, 16, 17, 100, 128, 333]))
+    T = int(rng.choice([2, 3, 7, 24, 40]))
+    H = int(rng.integers(1, 49))
+    Fe = int(rng.integers(1, 33))
+    if kind == lo.GENERATOR and B < 3:
+        B = 3            # the batch std of one or two rows is degenerate
+    gamma = float(rng.uniform(0.1, 2.0))
+    gen = torch.Generator(device="cuda:0").manual_seed(seed)
+    ts, req = _operands(kind, B, T, H, Fe, gen)
+    a = [t.clone().requires_grad_(q) for t, q in zip(ts, req)]
+    b = [t.clone().requires_grad_(q) for t, q in zip(ts, req)]
+    ref = _torch_loss(kind, a, gamma)
+    got = lo.fused_loss(kind, b, B, T, H, Fe, gamma)
+    tag = f"kind{kind} B{B} T{T} H{H} F{Fe}"
+    for i, v in enumerate(ref):
+        _close(got[i].detach(), v.detach(), LF, f"out[{i}] {tag}")
+    sum(ref).backward()
+    sum(got[i] for i in range(len(ref))).backward()
+    for i, (u, v) in enumerate(zip(a, b)):
+        if req[i]:
+            _close(v.grad, u.grad, LG, f"grad[{i}] {tag}")
