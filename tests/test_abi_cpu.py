@@ -82,3 +82,36 @@ def test_gru_module_matches_torch_parameter_layout_and_init():
         assert torch.equal(sd_o[k], sd_r[k]), f"{k}: same seed must give the same initial values"
     ref.load_state_dict(sd_o)       # interchange both ways
     ours.load_state_dict(sd_r)
+
+
+def test_argument_checks_of_the_struct_entry_points():
+    """The pair / head / loss / reduce entry points reject bad arguments before anything is launched."""
+    import timegan_amd as tg
+    from timegan_amd._lib import BackwardArgs, ForwardArgs, HeadArgs, ReduceJob
+    lb = tg.lib()
+    E_DIMS, E_NULL = -1, -2
+    fa, ba, ha = ForwardArgs(), BackwardArgs(), HeadArgs()          # all-zero structs
+    assert lb.tgru_forward_pair(None, None, None) == E_NULL
+    assert lb.tgru_forward_pair(ctypes.byref(fa), ctypes.byref(fa), None) == E_DIMS
+    assert lb.tgru_backward_pair(ctypes.byref(ba), ctypes.byref(ba), None) == E_DIMS
+    fa.B, fa.T, fa.In, fa.H, fa.L = 4, 3, 5, 6, 1
+    assert lb.tgru_forward_pair(ctypes.byref(fa), ctypes.byref(fa), None) == E_NULL
+    assert lb.tgru_head_forward_pair(None, ctypes.byref(ha), None) == E_NULL
+    assert lb.tgru_head_forward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
+    ha.M, ha.din, ha.dmid, ha.dout = 8, 33, 8, 8                    # input wider than the kernels cover
+    assert lb.tgru_head_forward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
+    ha.din, ha.dmid = 8, 65                                         # middle wider than the kernels cover
+    assert lb.tgru_head_backward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
+    assert lb.tgru_head_grad_floats(24, 24, 6) == 24 * 24 + 24 + 24 + 24 + 24 + 24 + 6 * 24 + 6
+    jobs = (ReduceJob * 2)()
+    assert lb.tgru_reduce_jobs(jobs, 0, None) == 0                  # nothing to do
+    assert lb.tgru_reduce_jobs(None, 2, None) == E_NULL
+    assert lb.tgru_reduce_jobs(jobs, 2, None) == E_NULL             # jobs without source / destination
+    assert lb.tgru_backward_reduce_jobs(None, jobs, 2) == E_NULL
+    lay = (ctypes.c_int64 * 4)()
+    assert lb.tgru_loss_layout(4, 24, 6, lay) == 0                  # generator loss: 2 x 144 column sums + squares
+    n_a, n_b, off_out, total = (int(v) for v in lay)
+    assert n_b == 2 * 24 * 6 and n_a == 4 + 3 * 256 + n_b and off_out == n_a + n_b and total > off_out + 3
+    assert lb.tgru_loss_layout(0, 24, 6, lay) == 0 and int(lay[1]) == 0
+    assert lb.tgru_loss_layout(7, 24, 6, lay) == E_DIMS
+    assert lb.tgru_loss_final(0, 4, 3, 5, 6, 1.0, None, None) == E_NULL
