@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--no-joint", action="store_true", help="skip the secondary 3-phase training probe")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per step instead of issuing its three launches from the host "
-                         "(measured slower here: 53 vs 48 us per step, the graph's inter-kernel gaps are larger)")
+                         "(measured slower here: 44.7 vs 41.3 us per step, the graph's inter-kernel gaps are larger)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the multi-rank code path (process group, all-reduces, graph capture of "
@@ -254,17 +254,23 @@ def main():
     if dist:
         device_barrier(dist, dev)
     torch.cuda.synchronize()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP events bracket GROUPS of steps (an event record costs about as much as a launch): device time per
+    # step = group time / group size, gaps between the step's kernels and between steps included
+    grp = 10 if args.steps % 10 == 0 and not do_ar else 1
+    ngrp = args.steps // grp
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev0[i].record()
+        if i % grp == 0:
+            ev0[i // grp].record()
         if graph is not None:
             graph.replay()
         else:
             runner.forward(x)
             runner.backward(dy)
-        ev1[i].record()
+        if i % grp == grp - 1:
+            ev1[i // grp].record()
         if do_ar:
             dist.all_reduce(runner.flat_grads)
     torch.cuda.synchronize()
@@ -276,7 +282,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    dev_ms = sorted(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+    dev_ms = sorted(a.elapsed_time(b) / grp for a, b in zip(ev0, ev1))
     dev_ms_avg = sum(dev_ms) / len(dev_ms)
     # the two halves of a step, timed apart in a short untimed pass of host-issued launches
     nh = min(args.steps, 50)
