@@ -255,8 +255,9 @@ def main():
         device_barrier(dist, dev)
     torch.cuda.synchronize()
     # HIP events bracket GROUPS of steps (an event record costs about as much as a launch): device time per
-    # step = group time / group size, gaps between the step's kernels and between steps included
-    grp = 10 if args.steps % 10 == 0 and not do_ar else 1
+    # step = group time / group size, gaps between the step's kernels and between steps included (and, with
+    # several ranks, the gradient all-reduce that ends each step)
+    grp = 10 if args.steps % 10 == 0 else 1
     ngrp = args.steps // grp
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
