@@ -5,7 +5,7 @@ The operator replaces `_VF.gru(...)` as reached from nn.GRU.forward
 outdated_files/TimeGANv1.py:61,139,220,299,376.
 """
 import ctypes
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -113,7 +113,6 @@ class _GRUFunction(torch.autograd.Function):
     def backward(ctx, dy, dh_n):
         B, T, In, H, L, layout = ctx.dims
         x, h0, y, lengths, toff, reserve, *weights = ctx.saved_tensors
-        w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
         dev = x.device
         dy = torch.zeros_like(y) if dy is None else dy.contiguous()   # only h_n was used
         dh_n = None if dh_n is None else dh_n.contiguous()

@@ -56,7 +56,6 @@ class _HeadFunction(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         x2 = saved.pop(0)
         params = [saved.pop(0) if pres else None for pres in ctx.present]
-        g0, b0, w1, c1, g1, b1, w2, c2 = params
         dev = x2.device
         dy2 = dy.contiguous().view(-1, dout)
         with on_device(dev):
@@ -77,21 +76,7 @@ class _HeadFunction(torch.autograd.Function):
                 args = HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
                                 *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), flag)
                 queue.add(lb.tgru_head_reduce_jobs, args, [ws, dparams, dy2], live, dev)
-        o = 0
-
-        def take(cnt, shape, present):
-            nonlocal o
-            v = dparams[o:o + cnt].view(shape) if present else None
-            o += cnt
-            return v
-        dw1 = take(dmid * din, (dmid, din), True)
-        dc1 = take(dmid, (dmid,), True)
-        dg0 = take(din, (din,), g0 is not None)
-        db0 = take(din, (din,), b0 is not None)
-        dg1 = take(dmid, (dmid,), g1 is not None)
-        db1 = take(dmid, (dmid,), b1 is not None)
-        dw2 = take(dout * dmid, (dout, dmid), w2 is not None)
-        dc2 = take(dout, (dout,), c2 is not None)
+        dg0, db0, dw1, dc1, dg1, db1, dw2, dc2 = _split_grads(dparams, din, dmid, dout, params)
         if dx is not None:
             dx = dx.view(dy.shape[:-1] + (din,))
         return (dx, None, dg0, db0, dw1, dc1, dg1, db1, dw2, dc2)

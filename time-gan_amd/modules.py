@@ -14,7 +14,7 @@ Differences, all output-preserving:
 `rnn_cls` exists so that the CPU tests and the CPU baseline can build the same networks on
 torch.nn.GRU; with it the forward takes the reference's literal pack -> GRU -> pad route.
 """
-from typing import Dict, Sequence
+from typing import Dict
 
 import torch
 import torch.nn as nn

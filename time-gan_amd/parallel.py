@@ -7,7 +7,7 @@ gradient that flows through its own shard, so parameter gradients are combined w
 SUM (never an average) over one flat bucket per optimiser group.
 """
 import os
-from typing import Iterable, List, Optional
+from typing import Iterable
 
 import torch
 import torch.distributed as dist
