@@ -232,6 +232,27 @@ int tgru_head_reduce_jobs(const tgru_head_args *a, tgru_reduce_job *jobs, int ma
 int tgru_reduce_jobs(const tgru_reduce_job *jobs, int n_jobs, tgru_stream_t stream);
 
 /*
+ * torch.optim.Adam (fused, no weight decay, no amsgrad) for up to TGRU_MAX_ADAM_JOBS small tensors (at
+ * most TGRU_MAX_ADAM_ELEMS elements each) in one launch: step += 1; m += (1-b1)(g-m);
+ * v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  `step` points to
+ * the tensor's own step counter (a device float, as torch keeps it for fused / capturable Adam); no two
+ * jobs of a launch may share a counter.  `skip` (device float or NULL): non-zero makes the launch a
+ * no-op, counters included -- the on-device form of the reference's
+ * `if d_loss > threshold: d_opt.step()` (outdated_files/TimeGANv1.py:805-808).
+ * Replaces torch's _foreach_add_ + _fused_adam_ launches.
+ */
+#define TGRU_MAX_ADAM_JOBS 64
+#define TGRU_MAX_ADAM_ELEMS 16384
+typedef struct tgru_adam_job {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq, *step;
+    int32_t n, reserved;
+} tgru_adam_job;
+int tgru_adam_jobs(const tgru_adam_job *jobs, int n_jobs, float lr, float beta1, float beta2, float eps,
+                   const float *skip, tgru_stream_t stream);
+
+/*
  * The loss expressions of the three training phases, fused (no reference FFI; they replace the
  * torch compositions at outdated_files/TimeGANv1.py:410-553):
  *   TGRU_LOSS_EMBED_SIDE     in = {x_tilde, x}                    out[0] = 10 sqrt(mse)            (:420-421)

@@ -48,6 +48,14 @@ class ReduceJob(ctypes.Structure):
                 ("dst", _vp)]
 
 
+class AdamJob(ctypes.Structure):
+    """tgru_adam_job of include/tgru.h."""
+    _fields_ = [(n, _vp) for n in ("param", "grad", "exp_avg", "exp_avg_sq", "step")] + \
+               [("n", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+MAX_ADAM_JOBS = 64        # TGRU_MAX_ADAM_JOBS
+MAX_ADAM_ELEMS = 16384    # TGRU_MAX_ADAM_ELEMS
 DEFER_REDUCE = 2          # TGRU_DEFER_REDUCE
 MAX_JOBS_PER_CALL = 32    # upper bound of jobs one backward call can owe (5 per layer, at most 4 layers on that path)
 
@@ -72,6 +80,7 @@ SIGNATURES = {
     "tgru_backward_reduce_jobs": (_i, [ctypes.POINTER(BackwardArgs), ctypes.POINTER(ReduceJob), _i]),
     "tgru_head_reduce_jobs": (_i, [ctypes.POINTER(HeadArgs), ctypes.POINTER(ReduceJob), _i]),
     "tgru_reduce_jobs": (_i, [ctypes.POINTER(ReduceJob), _i, _vp]),
+    "tgru_adam_jobs": (_i, [ctypes.POINTER(AdamJob), _i] + [ctypes.c_float] * 4 + [_vp, _vp]),
     "tgru_loss_layout": (_i, [_i] * 3 + [ctypes.POINTER(ctypes.c_int64)]),
     "tgru_loss_partial": (_i, [_i, _i, _vp] + [_i] * 4 + [_vp, _vp]),
     "tgru_loss_final": (_i, [_i] * 5 + [ctypes.c_float, _vp, _vp]),

@@ -13,6 +13,7 @@ from torch.optim import Adam
 from . import losses
 from .deferred import deferred_reductions
 from .modules import build_networks
+from .optim import AdamStep, init_adam_state
 import torch.distributed as dist
 
 from .parallel import all_reduce_grads, broadcast_parameters, multi_rank
@@ -48,19 +49,6 @@ class _GraphedStep:
         return self.static_out
 
 
-def _init_adam_state(opt):
-    """Creates Adam's per-parameter state now instead of inside the first step(): a step captured
-    into a graph must not contain the zero-initialisation of its own moment estimates."""
-    for group in opt.param_groups:
-        saved = [p.grad for p in group["params"]]
-        for p in group["params"]:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        opt._init_group(group, [], [], [], [], [], [])
-        for p, g in zip(group["params"], saved):
-            p.grad = g
-
-
 class TimeGANTrainer:
     """Owns the five networks and the six Adam optimisers of TimeGANv1.py:926-938.
 
@@ -87,9 +75,8 @@ class TimeGANTrainer:
         dp = multi_rank(group)
         self.use_graphs = (bool(use_graphs) and self.device.type == "cuda"
                            and (not dp or dist.get_backend(group) == "nccl"))
-        # On the GPU each Adam update is one fused multi-tensor kernel (torch's default foreach path
-        # issues a dozen launches per update, plus one per parameter for the bias corrections when
-        # the step counters live on the device, as graph capture needs them to).
+        # fused=True keeps Adam's step counters on the device, where the one-launch update (optim.AdamStep)
+        # and graph capture need them.
         kw_opt = {"fused": True} if self.device.type == "cuda" else {}
         if self.use_graphs:
             kw_opt["capturable"] = True
@@ -109,30 +96,25 @@ class TimeGANTrainer:
             self._g_d = _GraphedStep(self._joint_d_core, capture_mode=mode)
             self._thr = torch.tensor(self.d_threshold, device=self.device)   # the threshold the D graph reads
             self._thr_host = self.d_threshold
-            for o in self.opt.values():
-                _init_adam_state(o)
-            # One Adam launch per sub-step instead of one per network: an optimiser over the parameters of
-            # both networks whose per-parameter state IS the state of the two optimisers it stands for
-            # (the same dict objects), so phases that step them separately continue the same moments.
-            self._opt2 = {k: self._merged(k.split("+"), lr, kw_opt) for k in ("emb_side+rec", "g+sup", "emb_main+rec")}
             self._bufs = {}
+        # On the GPU the optimisers of a sub-step are stepped together by ONE kernel that works on their
+        # own state (optim.AdamStep), so the state is created up front.
+        self._adam = {}
+        if self.device.type == "cuda":
+            for o in self.opt.values():
+                init_adam_state(o)
 
     # -- helpers ---------------------------------------------------------------------------------
-    def _merged(self, names, lr, kw_opt):
-        params = [p for k in names for g in self.opt[k].param_groups for p in g["params"]]
-        merged = Adam(params, lr=lr, **kw_opt)
-        for k in names:
-            for p, st in self.opt[k].state.items():
-                merged.state[p] = st
-        return merged
-
-    def _step(self, *names):
-        """Adam update of the named optimisers (one merged launch in graph mode)."""
-        if self.use_graphs and "+".join(names) in self._opt2:
-            self._opt2["+".join(names)].step()
-        else:
+    def _step(self, *names, skip=None):
+        """Adam update of the named optimisers: one launch for all of them on the GPU."""
+        if self.device.type != "cuda":
             for k in names:
                 self.opt[k].step()
+            return
+        stepper = self._adam.get(names)
+        if stepper is None:
+            stepper = self._adam[names] = AdamStep([self.opt[k] for k in names], self.device)
+        stepper.step(skip)
 
     def _input_buffer(self, name: str, like: torch.Tensor) -> torch.Tensor:
         """Persistent device buffer that the captured graphs read their input from."""
@@ -182,7 +164,7 @@ class TimeGANTrainer:
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
             s_loss.backward()
         self._sync_grads("sup")
-        self.opt["sup"].step()
+        self._step("sup")
         return (s_loss.detach(),)
 
     def _joint_g_core(self, x, z):
@@ -211,8 +193,8 @@ class TimeGANTrainer:
         """Graph mode: the whole discriminator sub-step with the `d_loss > threshold` decision
         (TimeGANv1.py:805-808) taken ON THE DEVICE: forward and backward always run (an unused backward
         changes nothing: the gradients are zeroed before their next use, :765-769,796-799) and the
-        fused Adam kernel receives `d_loss <= threshold` as its skip flag -- the flag mixed-precision
-        training uses to drop a step -- which leaves parameters, moments and step counters untouched.
+        Adam kernel receives `d_loss <= threshold` as its skip flag, which leaves parameters, moments and
+        step counters untouched.
         No host synchronisation inside the iteration."""
         n = self.nets
         self._zero("emb", "sup", "g", "d")
@@ -222,11 +204,7 @@ class TimeGANTrainer:
             d_loss.backward()
         self._sync_grads("d")
         skip = (d_loss.detach() <= self._thr).to(torch.float32)
-        self.opt["d"].found_inf = skip
-        try:
-            self.opt["d"].step()
-        finally:
-            del self.opt["d"].found_inf
+        self._step("d", skip=skip)
         return (d_loss.detach(), 1.0 - skip)
 
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
@@ -240,8 +218,7 @@ class TimeGANTrainer:
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
             e_loss0.backward()
         self._sync_grads("emb", "rec")
-        self.opt["emb_side"].step()
-        self.opt["rec"].step()
+        self._step("emb_side", "rec")
         return float(e_loss0.detach())
 
     # -- phase 2: supervisor (TimeGANv1.py:662-683) -------------------------------------------------
@@ -255,7 +232,7 @@ class TimeGANTrainer:
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
             s_loss.backward()
         self._sync_grads("sup")
-        self.opt["sup"].step()
+        self._step("sup")
         return float(s_loss.detach())
 
     # -- phase 3: joint adversarial training (TimeGANv1.py:750-812) --------------------------------
@@ -303,7 +280,7 @@ class TimeGANTrainer:
                 with deferred_reductions():     # one launch sums the partial gradients of the whole pass
                     d_loss.backward()
                 self._sync_grads("d")
-                self.opt["d"].step()
+                self._step("d")
         return {"g_loss": [float(v) for v in torch.stack(g_losses).tolist()],
                 "e_loss": [float(v) for v in torch.stack(e_losses).tolist()],
                 "d_loss": float(d_loss.detach()), "d_stepped": stepped}
@@ -321,16 +298,14 @@ class TimeGANTrainer:
                 g_loss.backward()
             out["g_loss"].append(float(g_loss.detach()))
             self._sync_grads("g", "sup")
-            self.opt["g"].step()
-            self.opt["sup"].step()
+            self._step("g", "sup")
             self._zero("emb", "rec", "sup")
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
             with deferred_reductions():     # one launch sums the partial gradients of the whole pass
                 e_loss.backward()
             out["e_loss"].append(float(e_loss.detach()))
             self._sync_grads("emb", "rec")
-            self.opt["emb_main"].step()
-            self.opt["rec"].step()
+            self._step("emb_main", "rec")
         z = noise.pop(0) if noise is not None else torch.rand_like(x)
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z, group=self.group)
@@ -339,7 +314,7 @@ class TimeGANTrainer:
             with deferred_reductions():     # one launch sums the partial gradients of the whole pass
                 d_loss.backward()
             self._sync_grads("d")
-            self.opt["d"].step()
+            self._step("d")
         out["d_loss"] = float(d_loss.detach())
         out["d_stepped"] = stepped
         return out
