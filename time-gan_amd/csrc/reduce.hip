@@ -6,7 +6,7 @@
 // A caller may therefore ask the backward entry points to leave the partials alone (accumulate ==
 // TGRU_DEFER_REDUCE), collect the reductions as flat jobs
 //      dst[i] = sum over k < count of src[k * stride + i],   i < n
-// and run all of them here at once.  Workgroup = 32 elements x 32 groups of partials, summed in a fixed
+// and run all of them here at once.  Workgroup = 32 elements x 16 groups of partials, summed in a fixed
 // order, as in the per-call kernels.
 #include "../../include/tgru.h"
 #include "tgru_internal.h"
@@ -15,7 +15,7 @@ namespace tgru {
 namespace red {
 
 constexpr int kMaxJobs = TGRU_MAX_REDUCE_JOBS;
-constexpr int kElems = 32, kGroups = 32;
+constexpr int kElems = 32, kGroups = 16;
 
 struct JobTable {
     tgru_reduce_job job[kMaxJobs];
