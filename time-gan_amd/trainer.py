@@ -100,6 +100,7 @@ class TimeGANTrainer:
         # On the GPU the optimisers of a sub-step are stepped together by ONE kernel that works on their
         # own state (optim.AdamStep), so the state is created up front.
         self._adam = {}
+        self._one = torch.ones((), device=self.device)     # d loss / d loss, instead of a ones_like() per backward
         if self.device.type == "cuda":
             for o in self.opt.values():
                 init_adam_state(o)
@@ -152,7 +153,7 @@ class TimeGANTrainer:
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, self.lengths_of(x), group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            e_loss0.backward()
+            e_loss0.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_side", "rec")
         return (e_loss0.detach(),)
@@ -162,7 +163,7 @@ class TimeGANTrainer:
         self._zero("emb", "sup")
         s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            s_loss.backward()
+            s_loss.backward(self._one)
         self._sync_grads("sup")
         self._step("sup")
         return (s_loss.detach(),)
@@ -173,7 +174,7 @@ class TimeGANTrainer:
         g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
                                           group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            g_loss.backward()
+            g_loss.backward(self._one)
         self._sync_grads("g", "sup")
         self._step("g", "sup")
         return (g_loss.detach(),)
@@ -184,7 +185,7 @@ class TimeGANTrainer:
         e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
                                                      group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            e_loss.backward()
+            e_loss.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_main", "rec")
         return (e_loss.detach(),)
@@ -201,7 +202,7 @@ class TimeGANTrainer:
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
                                               group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            d_loss.backward()
+            d_loss.backward(self._one)
         self._sync_grads("d")
         skip = (d_loss.detach() <= self._thr).to(torch.float32)
         self._step("d", skip=skip)
@@ -216,7 +217,7 @@ class TimeGANTrainer:
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, t, group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            e_loss0.backward()
+            e_loss0.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_side", "rec")
         return float(e_loss0.detach())
@@ -230,7 +231,7 @@ class TimeGANTrainer:
         self._zero("emb", "sup")
         s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
         with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-            s_loss.backward()
+            s_loss.backward(self._one)
         self._sync_grads("sup")
         self._step("sup")
         return float(s_loss.detach())
@@ -278,7 +279,7 @@ class TimeGANTrainer:
             stepped = bool(d_loss > self.d_threshold)
             if stepped:
                 with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-                    d_loss.backward()
+                    d_loss.backward(self._one)
                 self._sync_grads("d")
                 self._step("d")
         return {"g_loss": [float(v) for v in torch.stack(g_losses).tolist()],
@@ -295,14 +296,14 @@ class TimeGANTrainer:
             g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
                                               group=self.group)
             with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-                g_loss.backward()
+                g_loss.backward(self._one)
             out["g_loss"].append(float(g_loss.detach()))
             self._sync_grads("g", "sup")
             self._step("g", "sup")
             self._zero("emb", "rec", "sup")
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
             with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-                e_loss.backward()
+                e_loss.backward(self._one)
             out["e_loss"].append(float(e_loss.detach()))
             self._sync_grads("emb", "rec")
             self._step("emb_main", "rec")
@@ -312,7 +313,7 @@ class TimeGANTrainer:
         stepped = bool(d_loss > self.d_threshold)
         if stepped:
             with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-                d_loss.backward()
+                d_loss.backward(self._one)
             self._sync_grads("d")
             self._step("d")
         out["d_loss"] = float(d_loss.detach())
