@@ -91,9 +91,7 @@ class TimeGANTrainer:
             mode = "thread_local" if dp else "global"
             self._g_emb = _GraphedStep(self._embedding_core, capture_mode=mode)
             self._g_sup = _GraphedStep(self._supervisor_core, capture_mode=mode)
-            self._g_gen = _GraphedStep(self._joint_g_core, capture_mode=mode)
-            self._g_e = _GraphedStep(self._joint_e_core, capture_mode=mode)
-            self._g_d = _GraphedStep(self._joint_d_core, capture_mode=mode)
+            self._g_joint = _GraphedStep(self._joint_iter_core, capture_mode=mode)
             self._thr = torch.tensor(self.d_threshold, device=self.device)   # the threshold the D graph reads
             self._thr_host = self.d_threshold
             self._bufs = {}
@@ -208,6 +206,18 @@ class TimeGANTrainer:
         self._step("d", skip=skip)
         return (d_loss.detach(), 1.0 - skip)
 
+    def _joint_iter_core(self, x, zb):
+        """Graph mode: a WHOLE joint iteration -- 10 x (generator + embedder sub-step) and the discriminator
+        sub-step with its on-device decision -- as one function of x and 11 noise tensors zb[0..10], so that
+        it can be captured into a single graph: one launch per iteration, every loss in its own tensor.
+        Returns (g_0, e_0, ..., g_9, e_9, d_loss, d_stepped)."""
+        outs = []
+        for i in range(10):
+            outs += self._joint_g_core(x, zb[i])
+            outs += self._joint_e_core(x)
+        outs += self._joint_d_core(x, zb[10])
+        return tuple(outs)
+
     # -- phase 1: embedding / recovery autoencoder (TimeGANv1.py:585-608) ---------------------------
     def embedding_step(self, x: torch.Tensor, t=None) -> float:
         if t is None:
@@ -247,41 +257,44 @@ class TimeGANTrainer:
             return self._joint_step_with_lengths(x, t, noise)
         noise = list(noise) if noise is not None else None
         if self.use_graphs:
-            # the graphs read x and z from persistent buffers: x is staged once per iteration, the noise
-            # is drawn (or copied) straight into its buffer
+            # one graph holds the whole iteration; it reads x and the 11 noise tensors from persistent
+            # buffers (x staged once, the noise drawn or copied straight into its buffer)
             x = self._staged("x", x)
-            zbuf = self._input_buffer("z", x)
-
-            def draw():
-                return zbuf.copy_(noise.pop(0)) if noise is not None else zbuf.uniform_()
-        else:
-            def draw():
-                return noise.pop(0) if noise is not None else torch.rand_like(x)
-        g_losses, e_losses = [], []
-        for _ in range(10):
-            z = draw()
-            (g_loss,) = (self._g_gen if self.use_graphs else self._joint_g_core)(x, z)
-            g_losses.append(g_loss.clone() if self.use_graphs else g_loss)
-            (e_loss,) = (self._g_e if self.use_graphs else self._joint_e_core)(x)
-            e_losses.append(e_loss.clone() if self.use_graphs else e_loss)
-        z = draw()
-        if self.use_graphs:
+            zb = self._bufs.get("z11")
+            if zb is None or zb.shape[1:] != x.shape:
+                zb = self._bufs["z11"] = torch.empty((11,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+            if noise is not None:
+                for i in range(11):
+                    zb[i].copy_(noise[i])
+            else:
+                zb.uniform_()
             if float(self._thr_host) != self.d_threshold:     # the threshold was changed since the last call
                 self._thr.fill_(self.d_threshold)
                 self._thr_host = self.d_threshold
-            d_loss, stepped_flag = self._g_d(x, z)
-            d_loss, stepped = d_loss.clone(), bool(stepped_flag)
-        else:
-            n = self.nets
-            self._zero("emb", "sup", "g", "d")
-            d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
-                                                  group=self.group)
-            stepped = bool(d_loss > self.d_threshold)
-            if stepped:
-                with deferred_reductions():     # one launch sums the partial gradients of the whole pass
-                    d_loss.backward(self._one)
-                self._sync_grads("d")
-                self._step("d")
+            outs = self._g_joint(x, zb)
+            vals = torch.stack(list(outs)).tolist()           # one copy to the host for all 22 numbers
+            return {"g_loss": vals[0:20:2], "e_loss": vals[1:20:2], "d_loss": vals[20], "d_stepped": vals[21] != 0.0}
+
+        def draw():
+            return noise.pop(0) if noise is not None else torch.rand_like(x)
+        g_losses, e_losses = [], []
+        for _ in range(10):
+            z = draw()
+            (g_loss,) = self._joint_g_core(x, z)
+            g_losses.append(g_loss)
+            (e_loss,) = self._joint_e_core(x)
+            e_losses.append(e_loss)
+        z = draw()
+        n = self.nets
+        self._zero("emb", "sup", "g", "d")
+        d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
+                                              group=self.group)
+        stepped = bool(d_loss > self.d_threshold)
+        if stepped:
+            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+                d_loss.backward(self._one)
+            self._sync_grads("d")
+            self._step("d")
         return {"g_loss": [float(v) for v in torch.stack(g_losses).tolist()],
                 "e_loss": [float(v) for v in torch.stack(e_losses).tolist()],
                 "d_loss": float(d_loss.detach()), "d_stepped": stepped}
