@@ -135,6 +135,47 @@ def test_mid_hidden_with_initial_state_and_ragged_lengths():
             assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
+@pytest.mark.parametrize("per_step", [True, False])
+def test_large_hidden_with_initial_state_and_ragged_lengths(per_step, monkeypatch):
+    """H > 128 in multiples of 32 runs one launch per time step (128 sequences x 32 units per workgroup);
+    TGRU_NO_STEP=1 keeps the persistent 16-sequence kernels covered on the same cases."""
+    import timegan_amd as tg
+    if per_step:
+        monkeypatch.delenv("TGRU_NO_STEP", raising=False)
+    else:
+        monkeypatch.setenv("TGRU_NO_STEP", "1")
+    for (B, T, In, H, L, lens) in ((300, 5, 40, 160, 2, [5] * 100 + [4] * 50 + [2] * 100 + [1] * 50),
+                                   (130, 3, 256, 256, 1, None),
+                                   (5, 7, 20, 192, 3, [7, 7, 3, 2, 1])):
+        torch.manual_seed(B + H)
+        ref = nn.GRU(In, H, L, batch_first=True)
+        ours = tg.GRU(In, H, L, batch_first=True).to("cuda:0")
+        ours.load_state_dict(ref.state_dict())
+        x = torch.rand(B, T, In)
+        h0 = torch.randn(L, B, H)
+        xr = x.clone().requires_grad_(True); hr0 = h0.clone().requires_grad_(True)
+        xo = x.clone().cuda().requires_grad_(True); ho0 = h0.clone().cuda().requires_grad_(True)
+        lens_ = [T] * B if lens is None else lens
+        pr = nn.utils.rnn.pack_padded_sequence(xr, lens_, batch_first=True, enforce_sorted=True)
+        yr, hnr = ref(pr, hr0)
+        yr, _ = nn.utils.rnn.pad_packed_sequence(yr, batch_first=True, padding_value=0, total_length=T)
+        yo, hno = ours(xo, ho0, lengths=lens)
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1))
+        gh = torch.randn(hnr.shape, generator=torch.Generator().manual_seed(2))
+        ((yr * gy).sum() + (hnr * gh).sum()).backward()
+        ((yo * gy.cuda()).sum() + (hno * gh.cuda()).sum()).backward()
+        tag = f"B{B}H{H}{'step' if per_step else 'persistent'}"
+        with torch.no_grad():   # inference: no reserve, the top layer's time-major copy lives in the workspace
+            yi, _ = ours(x.cuda(), h0.cuda(), lengths=lens)
+        assert_close(yi.cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " y (no_grad)")
+        assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " y")
+        assert_close(hno.detach().cpu().numpy(), hnr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " h_n")
+        assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dx")
+        assert_close(ho0.grad.cpu().numpy(), hr0.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dh0")
+        for (name, p_), (_, q_) in zip(ref.named_parameters(), ours.named_parameters()):
+            assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
+
+
 def test_reference_smoke_shapes_lengths_of_one_and_deep_stack():
     """run_embedding_test (TimeGANv1.py:77-94): x (10,150,5), t = ones(10) as a FLOAT tensor,
     H = 100, 50 layers -> (10,150,100); rows past length 1 are emb_linear(norm(0))."""

@@ -53,6 +53,14 @@ bool use_mid(int H) {
     return !(e && e[0] == '1');
 }
 
+// H > 128 (multiples of 32): one launch per time step (gru_step.hip); TGRU_NO_STEP=1 selects the
+// persistent 16-sequence kernels of gru_recurrent.hip instead.
+bool use_step(int B, int H) {
+    if (!gru_step_supported(B, H)) return false;
+    const char *e = getenv("TGRU_NO_STEP");
+    return !(e && e[0] == '1');
+}
+
 // reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
 size_t reserve_floats(const Dims &d) {
     size_t n = (size_t)d.L * 4 * align64(d.TBH());
@@ -88,7 +96,7 @@ int split_for(int M, int N, long K, int *kchunk) {
 }
 
 // backward workspace: dg | 2 x dy ping-pong | packed W_hh^T | bias partials | split-K slabs
-struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, total; int max_slabs; };
+struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, total; int max_slabs; };
 BwdWs bwd_ws(const Dims &d) {
     BwdWs w;
     size_t off = 0;
@@ -101,6 +109,7 @@ BwdWs bwd_ws(const Dims &d) {
     const bool vec_shape = gru_vec_supported(d.B, d.T, d.In, d.H, d.L);
     if (vec_shape && (size_t)gru_vec_workgroups(d.B) > nblk) nblk = (size_t)gru_vec_workgroups(d.B);
     if (gru_mid_supported(d.H)) nblk = (size_t)d.B;      // those kernels leave one bias partial per sequence
+    if (gru_step_supported(d.B, d.H) && (size_t)gru_step_bias_rows(d.B) > nblk) nblk = (size_t)gru_step_bias_rows(d.B);
     w.dbp = off; off += align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
@@ -124,6 +133,7 @@ BwdWs bwd_ws(const Dims &d) {
         if (need > slab_floats) slab_floats = need;
     }
     w.slabs = off; off += align64(slab_floats);
+    w.carry = off; off += gru_step_supported(d.B, d.H) ? align64((size_t)d.B * d.H) : 0;   // per-step kernels only
     w.total = off;
     return w;
 }
@@ -260,8 +270,8 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         g.bmap = id_map(d);
         g.cmap = id_map(d);
         TGRU_HIP(launch_gemm(g, true, true, 1, s));
-        const bool mid = use_mid(H);
-        if (!mid) TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
+        const bool mid = use_mid(H), stepk = use_step(B, H);
+        if (!mid && !stepk) TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
 
         FwdArgs f{};
         f.gi = gi; f.wp = wp; f.w_hh = w_hh[l]; f.b_hh = b_hh[l];
@@ -270,13 +280,16 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.y_int = nullptr;
         if (need_int) f.y_int = reserve ? reserve_y(d, reserve, l) : pp + (size_t)(l & 1) * align64(d.TBH());
         if (top && !reserve) f.y_int = nullptr;   // inference: nobody reads the top layer's copy
+        // the per-step kernels read h_{t-1} back from a time-major output
+        if (stepk && !f.y_int && layout != TGRU_LAYOUT_TBF) f.y_int = pp + (size_t)(l & 1) * align64(d.TBH());
         f.y_ext = top ? y : nullptr;
         f.ymap = ext_map(d, toff);
         f.gates = reserve ? reserve_gates(d, reserve, l) : nullptr;
         f.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
         f.lengths = lengths;
         f.B = B; f.T = T; f.H = H;
-        if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
+        if (stepk) TGRU_HIP(launch_gru_step_fwd(f, s));
+        else if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
         else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;
     }
@@ -407,7 +420,8 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         const float *in = l == 0 ? x : reserve_y(d, res, l - 1);
         // the four-sequence kernels read the caller's dy directly only in the padded layouts
         const bool mid = use_mid(H) && !(top && layout == TGRU_LAYOUT_PACKED);
-        if (!mid) TGRU_HIP(launch_pack_whh(w_hh[l], nullptr, wtp, H, s));
+        const bool stepk = use_step(B, H);
+        if (!mid && !stepk) TGRU_HIP(launch_pack_whh(w_hh[l], nullptr, wtp, H, s));
 
         BwdArgs b{};
         b.dy_int = top ? nullptr : workspace + w.dyb + (size_t)((l + 1) & 1) * dyb_stride;
@@ -422,9 +436,11 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         b.db_part = dbp;
         b.lengths = lengths;
         b.B = B; b.T = T; b.H = H;
-        if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
+        if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, s));
+        else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
         else TGRU_HIP(launch_gru_bwd(b, s));
-        TGRU_HIP(launch_bias_grad(dbp, mid ? B : nblk, H, db_ih[l], db_hh[l], accumulate, s));
+        TGRU_HIP(launch_bias_grad(dbp, stepk ? gru_step_bias_rows(B) : mid ? B : nblk, H, db_ih[l], db_hh[l],
+                                  accumulate, s));
 
         const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&
                                !(l == 0 && layout == TGRU_LAYOUT_PACKED);

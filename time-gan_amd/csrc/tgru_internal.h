@@ -191,6 +191,14 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
                                 const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
                                 int accumulate, hipStream_t s);
 
+// H > 128, H % 32 == 0: one launch per time step, 128 sequences x 32 units per workgroup (gru_step.hip).
+// Forward reads the state of step t-1 back from a.y_int (or from a.y_ext when that is time-major);
+// backward needs a (B,H) carry buffer and leaves gru_step_bias_rows(B) rows in a.db_part.
+bool gru_step_supported(int B, int H);
+int gru_step_bias_rows(int B);
+hipError_t launch_gru_step_fwd(const FwdArgs &a, hipStream_t s);
+hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s);
+
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
 // Two independent calls in one launch: workgroups [0, nwg0) serve g[0], the others g[1] (nwg1 may be 0).
