@@ -89,16 +89,19 @@ def _compare(res, ref, tag):
             assert_close(a, b, GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} {name}_l{l}")
 
 
-@pytest.fixture(params=["auto", "h24", "small", "per_layer"])
+@pytest.fixture(params=["auto", "h24", "small", "per_layer", "per_layer_guarded"])
 def kernel_path(request, monkeypatch):
     """auto: the kernels the library picks for the shape (H, In <= 32: one sequence per workgroup,
     gru_vec.hip); h24: the MFMA whole-stack kernels specialised for H = 24 (gru_h24.hip), which the
     library itself picks above 2048 sequences; small: the general MFMA whole-stack kernels
-    (gru_small.hip); per_layer: GEMM + recurrent kernels."""
-    for k in ("TGRU_FORCE_GENERIC", "TGRU_NO_H24", "TGRU_NO_VEC"):
+    (gru_small.hip); per_layer: GEMM + recurrent kernels; per_layer_guarded: the same with the GEMM's
+    guarded operand loads where the library would pick the unconditional ones."""
+    for k in ("TGRU_FORCE_GENERIC", "TGRU_NO_H24", "TGRU_NO_VEC", "TGRU_GEMM_GUARDED"):
         monkeypatch.delenv(k, raising=False)
-    if request.param == "per_layer":
+    if request.param.startswith("per_layer"):
         monkeypatch.setenv("TGRU_FORCE_GENERIC", "1")
+        if request.param == "per_layer_guarded":
+            monkeypatch.setenv("TGRU_GEMM_GUARDED", "1")
     elif request.param == "h24":
         monkeypatch.setenv("TGRU_NO_VEC", "1")
     elif request.param == "small":

@@ -5,6 +5,7 @@
 //   dX   = dGI . W_ih                (a_kc, !b_kc)
 //   dW_ih = dGI^T . X, dW_hh = dGH^T . H_prev   (!a_kc, !b_kc, split over the row dimension)
 #include "tgru_internal.h"
+#include <stdlib.h>
 
 namespace tgru {
 
@@ -13,7 +14,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+// FAST: every operand load is an unconditional 16-byte load (the launcher has checked alignment,
+// K and kchunk multiples of BK, no packed row maps, M / N multiples of 4 where they are contiguous);
+// rows and columns past the edge are clamped onto valid ones and their results are never stored.
+// A per-lane condition in front of a load costs a branch and serialises the loads of a tile.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool FAST>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     constexpr int LDA_S = BM + 4;
     constexpr int LDB_S = BN + 4;
@@ -75,9 +80,37 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
         }
     }
 
+    long a_fast[PA], b_fast[PB];   // FAST: element offset of the slot at k = 0
+    if (FAST) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int slot = min(tid + p * NTHREADS, SLOTS_A - 1);
+            if (A_KC) a_fast[p] = map_row(g.amap, min(m0 + (slot >> 2), g.M - 1)) * g.lda + ((slot & 3) << 2);
+            else a_fast[p] = (long)(slot / (BM / 4)) * g.lda + min(m0 + ((slot % (BM / 4)) << 2), g.M - 4);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int slot = min(tid + p * NTHREADS, SLOTS_B - 1);
+            if (B_KC) b_fast[p] = (long)min(n0 + (slot >> 2), g.N - 1) * g.ldb + ((slot & 3) << 2);
+            else b_fast[p] = (long)(slot / (BN / 4)) * g.ldb + min(n0 + ((slot % (BN / 4)) << 2), g.N - 4);
+        }
+    }
+
     float4 ra[PA], rb[PB];
 
-    auto load_tiles = [&](int k0) {
+    auto load_fast = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const float4 v = *reinterpret_cast<const float4 *>(g.A + a_fast[p] + (A_KC ? (long)k0 : (long)k0 * g.lda));
+            ra[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const float4 v = *reinterpret_cast<const float4 *>(g.Bm + b_fast[p] + (B_KC ? (long)k0 : (long)k0 * g.ldb));
+            rb[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto load_guarded = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -186,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (nkt > 0) {
-        load_tiles(kbeg);
+        if (FAST) load_fast(kbeg); else load_guarded(kbeg);
         store_tiles(0);
     }
     __syncthreads();
@@ -194,7 +227,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     const int lk = lane >> 5;
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);
+        if (kt + 1 < nkt) {
+            if (FAST) load_fast(kbeg + (kt + 1) * BK); else load_guarded(kbeg + (kt + 1) * BK);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[TM], b[TN];
@@ -238,18 +273,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// may every operand load of this product be an unconditional 16-byte load?
+static bool fast_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
+    if (getenv("TGRU_GEMM_GUARDED")) return false;   // tests: keep the guarded loads covered
+    if (!aligned16(g.A) || !aligned16(g.Bm) || (g.lda & 3) || (g.ldb & 3)) return false;
+    if (g.K < BK || (g.K % BK) || (nslabs > 1 && (g.kchunk % BK))) return false;
+    if (nslabs == 1 && g.kchunk < g.K) return false;
+    if ((a_kc && g.amap.mode == 2) || (!b_kc && g.bmap.mode != 0)) return false;   // B rows: identity map only
+    if (!a_kc && ((g.M & 3) || g.M < 4)) return false;
+    if (!b_kc && ((g.N & 3) || g.N < 4)) return false;
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
 static hipError_t launch_cfg(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
     dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, nslabs);
     dim3 block(NTHREADS);
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, g);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, g);
     else if (!a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, g);
     return hipGetLastError();
 }
 
@@ -259,8 +308,11 @@ hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipS
     const int waste128 = ((g.N + 127) / 128) * 128 - g.N;
     const int waste32 = ((g.N + 31) / 32) * 32 - g.N;
     const bool narrow = (g.N <= 96) || (waste128 * 4 > g.N && waste32 * 4 <= g.N);
-    if (narrow) return launch_cfg<128, 32, 4, 1>(g, a_kc, b_kc, nslabs, s);
-    return launch_cfg<128, 128, 2, 2>(g, a_kc, b_kc, nslabs, s);
+    const bool fast = fast_loads(g, a_kc, b_kc, nslabs);
+    if (narrow) return fast ? launch_cfg<128, 32, 4, 1, true>(g, a_kc, b_kc, nslabs, s)
+                            : launch_cfg<128, 32, 4, 1, false>(g, a_kc, b_kc, nslabs, s);
+    return fast ? launch_cfg<128, 128, 2, 2, true>(g, a_kc, b_kc, nslabs, s)
+                : launch_cfg<128, 128, 2, 2, false>(g, a_kc, b_kc, nslabs, s);
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slabs, long stride, int nslabs,
