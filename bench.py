@@ -350,6 +350,22 @@ def main():
             printed.append(True)
             print(json.dumps(out), flush=True)
 
+    # The secondary probes below run collectives that have only been rehearsed with one rank where this was
+    # written.  If one of them stalls, the headline result must still reach the driver: after the deadline
+    # rank 0 prints the line with what has been measured so far and every rank leaves.
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out.setdefault("timegan_training", {})["note_deadline"] = "secondary probes cut off at the deadline"
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "420")) + (0 if rank == 0 else 5), give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
     if not args.no_joint and args.workload == "c2":
         joint = {"note": "PyTorch autograd around the HIP GRU / head / loss kernels, batch %d per GPU, 6 features; "
                          "the eager figures are host-launch bound at this size" % B}
@@ -367,6 +383,7 @@ def main():
     if dist:
         device_barrier(dist, dev)
         dist.destroy_process_group()
+    watchdog.cancel()
 
 
 if __name__ == "__main__":
