@@ -157,8 +157,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwd s) {
             for (int d = 0; d < kDepth; ++d) {
                 const int kt = kt0 + d, cur = kt & 1;
                 if (kt < nkt) {
-#pragma unroll
-                    for (int kk = 0; kk < BK; kk += 2) {
+                    auto product = [&](int kk) {
                         const float av = As[cur][kk + lk][32 * wave + lrow];
                         const float b0 = Bs[cur][kk + lk][lrow];
                         const float b1 = Bs[cur][kk + lk][32 + lrow];
@@ -166,11 +165,17 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwd s) {
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc[2], 0, 0, 0);
-                    }
+                    };
+                    // the next tile goes to the other LDS buffer in the MIDDLE of this tile's products: its
+                    // LDS writes issue while the matrix pipe still has work queued
+#pragma unroll
+                    for (int kk = 0; kk < BK / 2; kk += 2) product(kk);
                     if (kt + 1 < nkt) {
                         store_tiles(cur ^ 1, ring[(d + 1) % kDepth]);
                         load_tiles(min(kt + 1 + kDepth, nkt - 1) * BK, ring[(d + 1) % kDepth]);
                     }
+#pragma unroll
+                    for (int kk = BK / 2; kk < BK; kk += 2) product(kk);
                     __syncthreads();
                 }
             }
@@ -303,17 +308,20 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwd s) {
             for (int d = 0; d < kDepth; ++d) {
                 const int kt = kt0 + d, cur = kt & 1;
                 if (kt < nkt) {
-#pragma unroll
-                    for (int kk = 0; kk < BK; kk += 4) {
+                    auto product = [&](int kk) {
                         const float a0 = As[cur][kk + lk][32 * wave + lrow], b0 = Bs[cur][kk + lk][lrow];
                         const float a1 = As[cur][kk + 2 + lk][32 * wave + lrow], b1 = Bs[cur][kk + 2 + lk][lrow];
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1], 0, 0, 0);
-                    }
-                    if (kt + 1 < nkt) {
+                    };
+#pragma unroll
+                    for (int kk = 0; kk < BK / 2; kk += 4) product(kk);
+                    if (kt + 1 < nkt) {   // in the middle of the tile's products, see the forward kernel
                         store_tiles(cur ^ 1, ring[(d + 1) % kDepth]);
                         load_tiles(min(kt + 1 + kDepth, nkt - 1) * BK, ring[(d + 1) % kDepth]);
                     }
+#pragma unroll
+                    for (int kk = BK / 2; kk < BK; kk += 4) product(kk);
                     __syncthreads();
                 }
             }
