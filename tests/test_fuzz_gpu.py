@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(rng):
-    H = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 25, 31, 32, 33, 40, 48, 64, 96]))
+    H = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 25, 31, 32, 33, 40, 48, 64, 96, 136, 160, 256]))
     In = int(rng.choice([1, 2, 5, 6, 7, 16, 24, 28, 31, 32, 33, 48]))
     L = int(rng.integers(1, 5))
     T = int(rng.choice([1, 2, 3, 7, 24, 33]))
