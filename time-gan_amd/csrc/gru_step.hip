@@ -10,7 +10,8 @@
 // workgroups.  The price is a kernel boundary per step (a few microseconds against about 30).
 //
 // forward, step t:   gh = h_{t-1} . W_hh^T for the tile's r, z, n columns (v_mfma_f32_32x32x2_f32,
-//                    LDS-tiled, register-staged double buffer), then the gate nonlinearities, the state
+//                    two LDS tile buffers fed from a register ring that holds the operand tiles of the
+//                    next kDepth products), then the gate nonlinearities, the state
 //                    update and every store of the step in the epilogue -- the three gate values of a
 //                    (sequence, unit) pair sit in the same lane and register of three accumulators.
 // backward, step t:  dh_t = dy_t + carry + dgh_{t+1} . W_hh (same tiling, K = 3H), then the gate
@@ -29,7 +30,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRows = 128;    // sequences per workgroup (four waves of 32)
 constexpr int kUnits = 32;    // hidden units per workgroup
 constexpr int kFwdBK = 16;    // k-tile of the forward product
-constexpr int kDepth = 3;     // operand tiles in flight ahead of the product
+#ifndef TGRU_STEP_DEPTH
+#define TGRU_STEP_DEPTH 4
+#endif
+constexpr int kDepth = TGRU_STEP_DEPTH;     // operand tiles in flight ahead of the product; even, so that the
+                                            // LDS buffer of a tile is known at compile time (kt & 1 == d & 1)
 
 struct StepFwd {
     FwdArgs f;
