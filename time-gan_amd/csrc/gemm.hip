@@ -250,6 +250,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 
     // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *Cz = g.C + (long)blockIdx.z * g.slab_stride;
+    float bias[TN];   // read once: inside the store loop the compiler must assume that C aliases it
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + lrow;
+        bias[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -262,8 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + lrow;
                 if (n < g.N) {
-                    float v = acc[i][j][r];
-                    if (g.bias) v += g.bias[n];
+                    float v = acc[i][j][r] + bias[j];
                     float *dst = Cz + crow * g.ldc + n;
                     if (g.accumulate) v += *dst;
                     *dst = v;
