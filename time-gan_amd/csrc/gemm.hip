@@ -36,9 +36,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    // Workgroup -> (row tile, column tile, k slab).  Consecutive workgroup ids go round the eight XCDs,
+    // each with its own L2, so the ids are dealt out in GROUPS that share operands: without split-K a
+    // group is one row tile with all its column tiles (the A rows are fetched from HBM by one XCD, once),
+    // with split-K a group is one k slab with all its tiles (each row of both operands likewise).  Group
+    // gi runs on XCD gi % 8, its members on consecutive ids of that XCD.
+    const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+    const int gsize = g.nslabs > 1 ? MT * NT : NT;
+    const int ngroups = g.nslabs > 1 ? g.nslabs : MT;
+    const int wid = blockIdx.x, grp = ((wid >> 3) / gsize) * 8 + (wid & 7), mem = (wid >> 3) % gsize;
+    if (grp >= ngroups) return;
+    const int tile_m = g.nslabs > 1 ? mem % MT : grp;
+    const int tile_n = g.nslabs > 1 ? mem / MT : mem;
+    const int slab = g.nslabs > 1 ? grp : 0;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int kbeg = slab * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     }
 
     // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *Cz = g.C + (long)blockIdx.z * g.slab_stride;
+    float *Cz = g.C + (long)slab * g.slab_stride;
     float bias[TN];   // read once: inside the store loop the compiler must assume that C aliases it
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -293,8 +306,12 @@ static bool fast_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>
-static hipError_t launch_cfg(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
-    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, nslabs);
+static hipError_t launch_cfg(const GemmArgs &g0, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
+    GemmArgs g = g0;
+    g.nslabs = nslabs;
+    const long MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+    const long gsize = nslabs > 1 ? MT * NT : NT, ngroups = nslabs > 1 ? nslabs : MT;
+    dim3 grid((unsigned)(8 * ((ngroups + 7) / 8) * gsize));
     dim3 block(NTHREADS);
     if (a_kc && b_kc)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, g);

@@ -60,6 +60,7 @@ struct GemmArgs {
     const float *bias;
     int M, N, K;
     int kchunk; long slab_stride;
+    int nslabs;         // set by launch_gemm
     int accumulate;     // only without split-K: C += result
     RowMap amap;        // rows of A (a_kc only)
     RowMap bmap;        // rows of B (!b_kc only): reduction index k -> caller row
