@@ -47,6 +47,29 @@ def main():
                 assert torch.allclose(w, v, rtol=1e-3, atol=2e-5), \
                     f"{name}: {net}.{k} differs, max {float((w - v).abs().max()):.3e}"
         print(name, "ok", flush=True)
+
+    # generation + post-hoc scores: the sharded code path (all-gather, sharded minibatches, all-reduced
+    # gradients and counts over RCCL) against the plain one
+    import numpy as np
+    rng = np.random.default_rng(3)
+    real = rng.uniform(0, 1, (41, 8, 5)).astype(np.float32)
+    synth = rng.uniform(0, 1, (41, 8, 5)).astype(np.float32)
+
+    def score(force):
+        parallel.FORCE_COLLECTIVES = force
+        group = dist.group.WORLD if force else None
+        torch.manual_seed(3)
+        tr = tg.TimeGANTrainer(cfg, device=dev, group=group)
+        xg = tr.generate_all(37, seed=5, chunk=16)
+        d = tg.scorer.discriminative_score(real, synth, dev, hidden=8, steps=10, batch=16, group=group)
+        p = tg.scorer.predictive_score(real, synth, dev, hidden=8, steps=10, batch=16, group=group)
+        return xg, d, p
+
+    x0, d0, p0 = score(False)
+    x1, d1, p1 = score(True)
+    assert x0.shape == (37, 8, 5) and torch.allclose(x0, x1, rtol=1e-5, atol=1e-6)
+    assert abs(d0 - d1) <= 1e-6 and abs(p0 - p1) <= 1e-4 * abs(p0) + 1e-6, (d0, d1, p0, p1)
+    print("generate/score ok", flush=True)
     dist.destroy_process_group()
     print("WORKER_OK", flush=True)
 

@@ -109,3 +109,49 @@ def test_shard_batch_covers_everything_once():
     from timegan_amd import parallel
     x = torch.arange(7)
     assert parallel.shard_batch(x).tolist() == list(range(7))      # world 1: identity
+
+
+def _score_inputs():
+    g = np.random.default_rng(3)
+    t = np.linspace(0, 3, 9)[None, :, None]
+    real = (np.sin(t * g.uniform(1, 2, (21, 1, 3)) + g.uniform(0, 3, (21, 1, 3))) + 1) / 2   # 21 windows: odd shards
+    synth = g.uniform(0, 1, real.shape)
+    return real.astype(np.float32), synth.astype(np.float32)
+
+
+def _generate_and_score(group=None):
+    """The generation + scoring flow of the water-quality config: n sequences from seeded noise, then the
+    two post-hoc scores, all sharded over the ranks of the group."""
+    import timegan_amd as tg
+    tr = _make_trainer(group)
+    x = tr.generate_all(7, seed=11, chunk=2)            # 7 sequences: shards of 4 and 3
+    real, synth = _score_inputs()
+    d = tg.scorer.discriminative_score(real, synth, "cpu", hidden=6, steps=12, batch=9, group=group,
+                                       rnn_cls=torch.nn.GRU)
+    p = tg.scorer.predictive_score(real, synth, "cpu", hidden=6, steps=12, batch=9, group=group,
+                                   rnn_cls=torch.nn.GRU)
+    return x, d, p
+
+
+def _score_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    x, d, p = _generate_and_score(dist.group.WORLD)
+    if rank == world - 1:          # the rank with the shorter shards reports: it must hold everything too
+        torch.save({"x": x, "d": d, "p": p}, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_generation_and_scores_match_single_process(tmp_path):
+    torch.set_num_threads(1)
+    x, d, p = _generate_and_score()
+    assert x.shape == (7, 8, 5)
+    path = str(tmp_path / "score.pt")
+    mp.spawn(_score_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = torch.load(path, weights_only=False)
+    np.testing.assert_allclose(got["x"].numpy(), x.numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(got["d"] - d) <= 1e-6            # accuracies are ratios of small integers
+    assert abs(got["p"] - p) <= 1e-4 * abs(p) + 1e-6

@@ -90,3 +90,26 @@ def shard_batch(x: torch.Tensor, group=None) -> torch.Tensor:
     base, rem = divmod(n, w)
     start = r * base + min(r, rem)
     return x[start:start + base + (1 if r < rem else 0)]
+
+
+def shard_bounds(n: int, group=None):
+    """(start, stop) of this rank's contiguous shard of n rows (the shards shard_batch cuts)."""
+    w, r = world_size(group), rank(group)
+    base, rem = divmod(n, w)
+    start = r * base + min(r, rem)
+    return start, start + base + (1 if r < rem else 0)
+
+
+def all_gather_rows(x_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Inverse of shard_batch: every rank passes its shard of an n_total-row tensor and receives the
+    whole tensor.  ONE all-gather; shards that are one row shorter travel padded."""
+    if not multi_rank(group):
+        return x_local
+    w = world_size(group)
+    base, rem = divmod(n_total, w)
+    cap = base + (1 if rem else 0)
+    send = x_local.new_zeros((cap,) + tuple(x_local.shape[1:]))
+    send[:x_local.shape[0]] = x_local
+    parts = [torch.empty_like(send) for _ in range(w)]
+    dist.all_gather(parts, send, group=group)
+    return torch.cat([p[:base + (1 if r < rem else 0)] for r, p in enumerate(parts)])

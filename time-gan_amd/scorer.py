@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .gru import GRU
+from .parallel import all_reduce_grads, broadcast_parameters, dist_sum, multi_rank, shard_bounds
 
 
 class GeneralRNN(nn.Module):
@@ -56,22 +57,35 @@ def split_real_synthetic(real: np.ndarray, synth: np.ndarray, seq_len: int) -> D
             "y_stock_train": rd[tr, -1, :], "y_synth_train": sd[tr, -1, :]}
 
 
-def _fit(model: nn.Module, x: torch.Tensor, y: torch.Tensor, loss_fn, steps: int, batch: int, lr: float,
-         generator: torch.Generator) -> None:
+def _fit(model: nn.Module, x: torch.Tensor, y: torch.Tensor, loss_sum, steps: int, batch: int, lr: float,
+         generator: torch.Generator, group=None) -> None:
+    """Adam on minibatches drawn with `generator` (every rank holds the same generator state, hence the
+    same minibatch).  `loss_sum(out, target)` returns the SUM of the per-element losses and their count;
+    with several ranks each takes a contiguous shard of the minibatch, the loss is that sum over the
+    GLOBAL count and the gradients are summed over ranks: the update equals the single-process one."""
+    broadcast_parameters([model], group=group)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     n = x.shape[0]
     for _ in range(steps):
-        idx = torch.randint(0, n, (min(batch, n),), generator=generator).to(x.device)
+        idx = torch.randint(0, n, (min(batch, n),), generator=generator)
+        lo, hi = shard_bounds(idx.numel(), group)
+        idx = idx[lo:hi].to(x.device)
         opt.zero_grad()
-        loss = loss_fn(model(x[idx].transpose(0, 1).contiguous()), y[idx])
-        loss.backward()
+        if idx.numel():
+            total, count = loss_sum(model(x[idx].transpose(0, 1).contiguous()), y[idx])
+        else:       # more ranks than rows in this minibatch: contribute nothing, keep the collectives aligned
+            total, count = sum(p.sum() for p in model.parameters()) * 0.0, 0
+        count = dist_sum(torch.tensor(float(count), device=x.device), group)
+        (total / count).backward()
+        all_reduce_grads([model], group=group)
         opt.step()
 
 
 def discriminative_score(real: np.ndarray, synth: np.ndarray, device, hidden: int = 24, steps: int = 200,
-                         batch: int = 128, lr: float = 1e-3, seed: int = 0) -> float:
+                         batch: int = 128, lr: float = 1e-3, seed: int = 0, group=None, rnn_cls=GRU) -> float:
     """|accuracy - 0.5| of a GRU classifier real (1) vs synthetic (0), trained on 75 % of the pairs
-    and evaluated on the rest.  0 = indistinguishable."""
+    and evaluated on the rest.  0 = indistinguishable.  With a process group every rank passes the same
+    arrays and gets the same score: minibatches and the test set are sharded over the ranks."""
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     real_t = torch.as_tensor(np.asarray(real), dtype=torch.float32, device=device)
@@ -80,34 +94,43 @@ def discriminative_score(real: np.ndarray, synth: np.ndarray, device, hidden: in
     n_train = int(.75 * n)
     cfg = {"rnn": {"type": "gru", "dim_input": real_t.shape[2], "dim_output": 1, "dim_hidden": hidden,
                    "num_layers": 1, "dropout": 0.0, "bidirectional": "false"}}
-    clf = GeneralRNN(cfg).to(device)
+    clf = GeneralRNN(cfg, rnn_cls=rnn_cls).to(device)
     x = torch.cat([real_t[:n_train], synth_t[:n_train]])
     y = torch.cat([torch.ones(n_train, device=device), torch.zeros(n_train, device=device)])
-    bce = nn.BCELoss()
-    _fit(clf, x, y, lambda out, tgt: bce(out[-1, :, 0], tgt), steps, batch, lr, g)
+    bce = nn.BCELoss(reduction="sum")
+    _fit(clf, x, y, lambda out, tgt: (bce(out[-1, :, 0], tgt), tgt.numel()), steps, batch, lr, g, group)
     with torch.no_grad():
-        xt = torch.cat([real_t[n_train:], synth_t[n_train:]]).transpose(0, 1).contiguous()
+        xt = torch.cat([real_t[n_train:], synth_t[n_train:]])
         yt = torch.cat([torch.ones(n - n_train), torch.zeros(n - n_train)]).to(device)
-        acc = ((clf(xt)[-1, :, 0] > 0.5).float() == yt).float().mean().item()
+        lo, hi = shard_bounds(xt.shape[0], group)
+        hits = xt.new_zeros(())
+        if hi > lo:
+            hits = ((clf(xt[lo:hi].transpose(0, 1).contiguous())[-1, :, 0] > 0.5).float() == yt[lo:hi]).float().sum()
+        acc = (dist_sum(hits, group) / xt.shape[0]).item()
     return abs(acc - 0.5)
 
 
 def predictive_score(real: np.ndarray, synth: np.ndarray, device, hidden: int = 24, steps: int = 200,
-                     batch: int = 128, lr: float = 1e-3, seed: int = 0) -> float:
+                     batch: int = 128, lr: float = 1e-3, seed: int = 0, group=None, rnn_cls=GRU) -> float:
     """Mean absolute error, on the real test windows, of a GRU trained on synthetic windows to predict
-    the last step of a window (y of discriminative.py:74-78) from the steps before it."""
+    the last step of a window (y of discriminative.py:74-78) from the steps before it.  Sharded over
+    the ranks of `group` like discriminative_score."""
     g = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed)
     sp = split_real_synthetic(real, synth, np.asarray(real).shape[1])
     f = sp["X_synth_train"].shape[2]
     cfg = {"rnn": {"type": "gru", "dim_input": f, "dim_output": f, "dim_hidden": hidden,
                    "num_layers": 1, "dropout": 0.0, "bidirectional": "false"}}
-    model = GeneralRNN(cfg).to(device)
+    model = GeneralRNN(cfg, rnn_cls=rnn_cls).to(device)
     xs = torch.as_tensor(sp["X_synth_train"][:, :-1, :], dtype=torch.float32, device=device)
     ys = torch.as_tensor(sp["y_synth_train"], dtype=torch.float32, device=device)
-    l1 = nn.L1Loss()
-    _fit(model, xs, ys, lambda out, tgt: l1(out[-1], tgt), steps, batch, lr, g)
+    l1 = nn.L1Loss(reduction="sum")
+    _fit(model, xs, ys, lambda out, tgt: (l1(out[-1], tgt), tgt.numel()), steps, batch, lr, g, group)
     with torch.no_grad():
         xr = torch.as_tensor(sp["X_stock_test"][:, :-1, :], dtype=torch.float32, device=device)
         yr = torch.as_tensor(sp["y_stock_test"], dtype=torch.float32, device=device)
-        return l1(model(xr.transpose(0, 1).contiguous())[-1], yr).item()
+        lo, hi = shard_bounds(xr.shape[0], group)
+        err = xr.new_zeros(())
+        if hi > lo:
+            err = l1(model(xr[lo:hi].transpose(0, 1).contiguous())[-1], yr[lo:hi])
+        return (dist_sum(err, group) / yr.numel()).item()

@@ -16,7 +16,7 @@ from .modules import build_networks
 from .optim import AdamStep, init_adam_state
 import torch.distributed as dist
 
-from .parallel import all_reduce_grads, broadcast_parameters, multi_rank
+from .parallel import all_gather_rows, all_reduce_grads, broadcast_parameters, multi_rank, shard_batch
 
 
 class _GraphedStep:
@@ -338,6 +338,19 @@ class TimeGANTrainer:
         n = self.nets
         t = [z.shape[1]] * z.shape[0] if t is None else t
         return losses.inference(n["sup"], n["g"], n["rec"], z, t)
+
+    @torch.no_grad()
+    def generate_all(self, n_total: int, seed: int = 0, chunk: int = 4096) -> torch.Tensor:
+        """n_total synthetic sequences (the inference path of TimeGANv1.py:556-570 on noise U[0,1)), sharded
+        over the ranks of the group: every rank draws the SAME noise from `seed`, generates its contiguous
+        shard (in chunks of `chunk` sequences) and one all-gather hands every rank all n_total sequences,
+        equal to what a single process generates from that seed."""
+        feats = int(self.cfg["g"]["dim_latent"])
+        z = torch.rand(n_total, self.seq_len, feats, generator=torch.Generator().manual_seed(seed))
+        z = shard_batch(z, self.group).to(self.device)
+        parts = [self.generate(z[i:i + chunk]) for i in range(0, z.shape[0], chunk)]
+        x = torch.cat(parts) if parts else z.new_zeros((0, self.seq_len, int(self.cfg["rec"]["dim_output"])))
+        return all_gather_rows(x, n_total, self.group)
 
     def state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
         return {k: m.state_dict() for k, m in self.nets.items()}
