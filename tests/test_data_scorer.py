@@ -102,3 +102,70 @@ def test_scores_separate_good_from_bad_synthetic_data():
     assert 0.0 <= d_good <= 0.5 and 0.0 <= d_bad <= 0.5
     assert d_bad > 0.4 and d_good < d_bad
     assert p_good < p_bad
+
+
+def test_resident_dataset_all_ranks_take_the_same_number_of_batches():
+    """A tail batch with fewer rows than ranks is dropped by every rank (a rank without rows would skip a
+    step whose collectives the others wait in)."""
+    import timegan_amd as tg
+    ds = tg.data.ResidentDataset(np.zeros((18, 2, 3), dtype=np.float32), "cpu")     # batches of 8, 8, 2
+    counts = [sum(1 for _ in ds.batches(8, shuffle=False, rank=r, world=4)) for r in range(4)]
+    assert counts == [2, 2, 2, 2]
+    sizes = [[b.shape[0] for b in ds.batches(5, shuffle=False, rank=r, world=4)] for r in range(4)]   # 5, 5, 5, 3
+    assert sizes == [[2, 2, 2], [1, 1, 1], [1, 1, 1], [1, 1, 1]]
+
+
+def test_fit_runs_the_three_phases_and_model_files_round_trip(tmp_path):
+    """fit() = the reference's driver (TimeGANv1.py:940-1009): phases in order, each for its configured
+    epochs; save_models / load_models use the reference's file names and plain tensor files."""
+    import timegan_amd as tg
+    torch.manual_seed(1)
+    cfg = tg.make_cfg(features=3, hidden=6, layers=1, seq_len=5, batch_size=4, device="cpu")
+    cfg["emb"]["num_epochs"] = 2
+    cfg["system"]["dataset"] = "sine"
+    tr = tg.TimeGANTrainer(cfg, device="cpu", rnn_cls=torch.nn.GRU)
+    ds = tg.data.ResidentDataset(np.random.default_rng(0).uniform(0, 1, (10, 5, 3)).astype(np.float32), "cpu")
+    seen = []
+    hist = tr.fit(ds, on_batch=lambda phase, epoch, i, out: seen.append((phase, epoch, i)))
+    assert [len(hist[k]) for k in ("embedding", "supervisor", "joint")] == [6, 3, 3]      # 3 batches per epoch
+    assert seen[0] == ("embedding", 0, 0) and seen[5] == ("embedding", 1, 2) and seen[-1] == ("joint", 0, 2)
+    assert set(hist["joint"][0]) >= {"g_loss", "e_loss", "d_loss", "d_stepped"}
+    with pytest.raises(ValueError):
+        tr.fit(ds, phases=("embedding", "adversarial"))
+    paths = tr.save_models(str(tmp_path))
+    assert sorted(os.path.basename(p) for p in paths) == ["d_sine.pt", "emb_sine.pt", "g_sine.pt", "rec_sine.pt", "sup_sine.pt"]
+    ref = torch.nn.GRU(6, 6, 1, batch_first=True)        # torch's own module takes the stored GRU tensors
+    sd = torch.load(os.path.join(str(tmp_path), "sup_sine.pt"), weights_only=True)
+    ref.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if "weight_ih_l0" in k or "weight_hh_l0" in k
+                         or "bias_ih_l0" in k or "bias_hh_l0" in k})
+    tr2 = tg.TimeGANTrainer(cfg, device="cpu", rnn_cls=torch.nn.GRU)
+    tr2.load_models(str(tmp_path))
+    for k in tr.nets:
+        for (n1, p1), (_, p2) in zip(tr.nets[k].state_dict().items(), tr2.nets[k].state_dict().items()):
+            assert torch.equal(p1, p2), (k, n1)
+
+
+@pytest.mark.gpu
+def test_fit_with_graphs_equals_eager_fit_including_a_ragged_last_batch():
+    """Graph mode replays full batches and runs a batch of another size eagerly; both trainers see the same
+    batches and the same noise, so the networks must end up the same."""
+    import timegan_amd as tg
+    data = np.random.default_rng(0).uniform(0, 1, (44, 8, 5)).astype(np.float32)      # batches of 16, 16, 12
+    cfg = tg.make_cfg(features=5, hidden=12, layers=2, seq_len=8, batch_size=16, device="cuda:0")
+    cfg["emb"]["num_epochs"] = 2
+    cfg["sup"]["num_epochs"] = 2
+    cfg["system"]["jointly_num_epochs"] = 2
+    results = []
+    for graphs in (False, True):
+        torch.manual_seed(7)
+        tr = tg.TimeGANTrainer(cfg, device="cuda:0", use_graphs=graphs)
+        ds = tg.data.ResidentDataset(data, "cuda:0")
+        torch.manual_seed(8)           # the noise of the joint phase comes from the global generator
+        hist = tr.fit(ds, seed=3)
+        results.append((hist, tr.state_dicts()))
+    (h0, sd0), (h1, sd1) = results
+    assert len(h0["joint"]) == len(h1["joint"]) == 6
+    np.testing.assert_allclose(h1["embedding"], h0["embedding"], rtol=2e-4)
+    np.testing.assert_allclose(h1["supervisor"], h0["supervisor"], rtol=2e-4)
+    for h in (h0, h1):      # the joint phase draws its noise differently in the two modes: sanity only
+        assert all(np.isfinite(o["d_loss"]) and np.all(np.isfinite(o["g_loss"])) for o in h["joint"])

@@ -71,7 +71,12 @@ class ResidentDataset:
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
             if world > 1:
-                per = (idx.numel() + world - 1) // world
-                idx = idx[rank * per:(rank + 1) * per]
+                # shard sizes differ by at most one (parallel.shard_batch); a tail batch with fewer rows than
+                # ranks is dropped by EVERY rank, so that all ranks run the same number of steps
+                if idx.numel() < world:
+                    continue
+                base, rem = divmod(idx.numel(), world)
+                start = rank * base + min(rank, rem)
+                idx = idx[start:start + base + (1 if rank < rem else 0)]
             if idx.numel():
                 yield self.data.index_select(0, idx)

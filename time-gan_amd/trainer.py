@@ -352,6 +352,62 @@ class TimeGANTrainer:
         x = torch.cat(parts) if parts else z.new_zeros((0, self.seq_len, int(self.cfg["rec"]["dim_output"])))
         return all_gather_rows(x, n_total, self.group)
 
+    # -- the three phases over a dataset (TimeGANv1.py:573-812 loops, :940-1009 driver) ---------------
+    def fit(self, dataset, phases: Sequence[str] = ("embedding", "supervisor", "joint"), batch_size: Optional[int] = None,
+            seed: int = 0, on_batch=None) -> Dict[str, List]:
+        """Runs the named phases in order, each for its configured number of epochs
+        (cfg['emb']['num_epochs'], cfg['sup']['num_epochs'], cfg['system']['jointly_num_epochs'],
+        TimeGANv1.py:581,658,745) over `dataset` (data.ResidentDataset, or anything with the same
+        `batches(batch_size, shuffle, generator, rank, world)`); `batch_size` is the GLOBAL batch, of which
+        every rank of the group takes its shard.  Returns the per-batch losses of each phase.
+        `on_batch(phase, epoch, index, result)` is called after every batch (logging hooks, early stops by
+        raising StopIteration)."""
+        from .parallel import rank as rank_of, world_size
+        bs = int(batch_size if batch_size is not None else self.cfg["system"]["batch_size"])
+        epochs = {"embedding": int(self.cfg["emb"]["num_epochs"]), "supervisor": int(self.cfg["sup"]["num_epochs"]),
+                  "joint": int(self.cfg["system"]["jointly_num_epochs"])}
+        steps = {"embedding": self.embedding_step, "supervisor": self.supervisor_step, "joint": self.joint_step}
+        gen = torch.Generator().manual_seed(seed)       # same permutation on every rank
+        r, w = rank_of(self.group), world_size(self.group)
+        history = {}
+        try:
+            for phase in phases:
+                if phase not in steps:
+                    raise ValueError("The step should be: embedding, supervisor or joint")   # TimeGANv1.py:1012
+                log = history.setdefault(phase, [])
+                for epoch in range(epochs[phase]):
+                    for i, x in enumerate(dataset.batches(bs, shuffle=True, generator=gen, rank=r, world=w)):
+                        out = steps[phase](x)
+                        log.append(out)
+                        if on_batch is not None:
+                            on_batch(phase, epoch, i, out)
+        except StopIteration:
+            pass
+        return history
+
+    def save_models(self, directory: str, dataset: Optional[str] = None, nets: Optional[Sequence[str]] = None) -> List[str]:
+        """state_dicts as the files the reference writes and reads back between its phases:
+        `<directory>/<net>_<dataset>.pt` for emb, rec, sup, g, d (TimeGANv1.py:953-954,976,1006,1009);
+        tensors are moved to the CPU first, as there.  Parameter names and shapes are torch's, so the files
+        load into the reference's modules and the reference's files load here."""
+        import os
+        name = dataset if dataset is not None else self.cfg["system"].get("dataset", "synthetic")
+        os.makedirs(directory, exist_ok=True)
+        paths = []
+        for k in (nets if nets is not None else ("emb", "rec", "sup", "g", "d")):
+            path = os.path.join(directory, f"{k}_{name}.pt")
+            torch.save({n: t.detach().cpu() for n, t in self.nets[k].state_dict().items()}, path)
+            paths.append(path)
+        return paths
+
+    def load_models(self, directory: str, dataset: Optional[str] = None, nets: Optional[Sequence[str]] = None) -> None:
+        """Inverse of save_models (tensor-only files: loaded with weights_only=True)."""
+        import os
+        name = dataset if dataset is not None else self.cfg["system"].get("dataset", "synthetic")
+        for k in (nets if nets is not None else ("emb", "rec", "sup", "g", "d")):
+            sd = torch.load(os.path.join(directory, f"{k}_{name}.pt"), map_location=self.device, weights_only=True)
+            self.nets[k].load_state_dict(sd)
+
     def state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
         return {k: m.state_dict() for k, m in self.nets.items()}
 
