@@ -129,6 +129,34 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
                           int M, int N, int K, tgru_stream_t stream);
 
 /*
+ * LayerNorm over the last dimension, rows of `width` floats (a multiple of 4, at most 128): the
+ * nn.LayerNorm(dim_hidden) stages of the heads (outdated_files/TimeGANv1.py:45,67) at hidden sizes the
+ * fused head kernels do not cover.  forward: y = (x - mean) * rstd * gamma + beta, stats[2r] = mean,
+ * stats[2r + 1] = rstd (biased variance + eps, torch.nn.functional.layer_norm).  backward: dx (NULL: not
+ * wanted), dgamma / dbeta (NULL: not wanted; accumulate 0 / 1) from x, dy and the saved stats; `workspace`
+ * holds one partial column sum per workgroup, added in a fixed order.  gamma / beta may be NULL (1 / 0).
+ */
+int tgru_layer_norm_supported(int width);
+size_t tgru_layer_norm_backward_workspace_bytes(long rows, int width);
+int tgru_layer_norm_forward(const float *x, const float *gamma, const float *beta, float *y, float *stats,
+                            long rows, int width, float eps, tgru_stream_t stream);
+int tgru_layer_norm_backward(const float *x, const float *dy, const float *stats, const float *gamma, float *dx,
+                             float *dgamma, float *dbeta, float *workspace, long rows, int width, int accumulate,
+                             tgru_stream_t stream);
+
+/*
+ * Weight gradient of a Linear layer over many rows:  dw (out_f, in_f) (=|+=) dy (rows, out_f)^T . x (rows, in_f),
+ * the term autograd forms for the Linear layers around the GRU (outdated_files/TimeGANv1.py:39-50,67-68)
+ * when the row count is that of a whole batch of sequences (B*T rows against 96 x 96 outputs: a product
+ * that has to be split over the ROWS to fill the GPU).  fp32 MFMA GEMM split over the rows, partial
+ * results in `workspace` (tgru_linear_weight_grad_workspace_bytes), summed in a fixed order.
+ * accumulate: 0 or 1.
+ */
+size_t tgru_linear_weight_grad_workspace_bytes(int rows, int out_f, int in_f);
+int tgru_linear_weight_grad(const float *dy, const float *x, float *dw, float *workspace,
+                            int rows, int out_f, int in_f, int accumulate, tgru_stream_t stream);
+
+/*
  * Two independent calls evaluated together, e.g. the embedder and the generator of one training step
  * (outdated_files/TimeGANv1.py:517-518), or the recovery and supervisor networks applied to the same
  * latent sequence (:436-437).  The structs carry exactly the arguments of tgru_forward / tgru_backward

@@ -84,6 +84,15 @@ def test_gru_module_matches_torch_parameter_layout_and_init():
     ours.load_state_dict(sd_r)
 
 
+def test_linear_weight_grad_argument_checks():
+    from timegan_amd import _lib
+    lb = _lib.lib()
+    assert lb.tgru_linear_weight_grad_workspace_bytes(0, 96, 96) == 0
+    assert lb.tgru_linear_weight_grad_workspace_bytes(24576, 96, 96) >= 96 * 96 * 4
+    assert lb.tgru_linear_weight_grad(None, None, None, None, 16, 8, 8, 0, None) != 0      # NULL pointers
+    assert lb.tgru_linear_weight_grad(None, None, None, None, 0, 8, 8, 0, None) != 0       # no rows
+
+
 def test_argument_checks_of_the_struct_entry_points():
     """The pair / head / loss / reduce entry points reject bad arguments before anything is launched."""
     import timegan_amd as tg

@@ -1,6 +1,8 @@
 """GPU tests of the fused dense head (tgru_head_forward / tgru_head_backward) against the torch
 modules it replaces (nn.LayerNorm / nn.Linear / ReLU evaluated on the CPU in fp32), for every head
 shape the five TimeGAN networks use and for ragged sizes."""
+import copy
+
 import pytest
 import torch
 import torch.nn as nn
@@ -87,6 +89,64 @@ def test_head_3d_input_and_wide_fallback():
     ref = _torch_head({k: (None if v is None else v.cpu()) for k, v in m2.items()}, x.cpu())
     assert y2.shape == (4, 5, 24)
     assert_close(y2.detach().cpu().numpy(), ref.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y 3d")
+
+
+@pytest.mark.parametrize("rows,din,dmid,dout", [(4096, 96, 96, 96), (3000, 28, 96, 96), (2500, 30, 70, 45)])
+def test_wide_head_weight_gradient_split_over_rows(rows, din, dmid, dout):
+    """Heads wider than the fused kernels: torch's modules, with the Linear weight gradients (out x in
+    products over all rows) formed by the library's row-split GEMM; everything against torch on the CPU."""
+    from timegan_amd.head import WIDE_LINEAR_MIN_ROWS, head_apply, supported
+    assert rows >= WIDE_LINEAR_MIN_ROWS
+    ref = _modules(din, dmid, dout, True, True, seed=3)
+    ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, din, generator=g)
+    dy = torch.randn(rows, dout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True)
+    assert not supported(xo, ours["lin1"], ours["lin2"])
+    yr = _torch_head(ref, xr)
+    yo = head_apply(xo, ours["ln0"], ours["lin1"], ours["ln1"], ours["lin2"])
+    (yr * dy).sum().backward()
+    (yo * dy.cuda()).sum().backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), 1e-4, 1e-5, "y")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), 1e-3, 1e-4, "dx")     # vendor GEMMs on both sides
+    for k in ref:
+        if ref[k] is None:
+            continue
+        for (name, pr), (_, po) in zip(ref[k].named_parameters(), ours[k].named_parameters()):
+            assert_close(po.grad.cpu().numpy(), pr.grad.numpy(), 1e-3, 1e-4, f"d{k}.{name}")
+
+
+@pytest.mark.parametrize("rows,width,affine", [(4096, 96, True), (2051, 28, True), (3000, 128, True), (2500, 4, True),
+                                                 (2048, 64, False)])
+def test_wide_layer_norm_matches_torch_cpu(rows, width, affine):
+    """tgru_layer_norm_forward / backward behind nn.LayerNorm's parameters, against torch on the CPU."""
+    from timegan_amd.head import wide_layer_norm
+    torch.manual_seed(rows + width)
+    ref = nn.LayerNorm(width, elementwise_affine=affine)
+    if affine:
+        with torch.no_grad():
+            ref.weight.uniform_(0.5, 1.5)
+            ref.bias.uniform_(-0.5, 0.5)
+    ours = copy.deepcopy(ref).to("cuda:0")
+    x = torch.randn(rows // 8, 8, width) * 2 + 0.5       # 3-D input: the leading shape must survive
+    dy = torch.randn(rows // 8, 8, width)
+    xr = x.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True)
+    yr = ref(xr)
+    yo = wide_layer_norm(xo, ours)
+    assert yo.shape == yr.shape
+    (yr * dy).sum().backward()
+    (yo * dy.cuda()).sum().backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    if affine:
+        assert_close(ours.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dgamma")
+        assert_close(ours.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dbeta")
+    # widths the kernels do not take fall back to torch
+    odd = nn.LayerNorm(30).to("cuda:0")
+    assert wide_layer_norm(torch.randn(4096, 30, device="cuda:0"), odd).shape == (4096, 30)
 
 
 PAIRS = [

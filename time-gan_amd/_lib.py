@@ -71,6 +71,12 @@ SIGNATURES = {
     "tgru_forward_pair": (_i, [ctypes.POINTER(ForwardArgs)] * 2 + [_vp]),
     "tgru_backward_pair": (_i, [ctypes.POINTER(BackwardArgs)] * 2 + [_vp]),
     "tgru_input_projection": (_i, [_vp] * 4 + [_i] * 3 + [_vp]),
+    "tgru_layer_norm_supported": (_i, [_i]),
+    "tgru_layer_norm_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long, _i]),
+    "tgru_layer_norm_forward": (_i, [_vp] * 5 + [ctypes.c_long, _i, ctypes.c_float, _vp]),
+    "tgru_layer_norm_backward": (_i, [_vp] * 8 + [ctypes.c_long, _i, _i, _vp]),
+    "tgru_linear_weight_grad_workspace_bytes": (ctypes.c_size_t, [_i] * 3),
+    "tgru_linear_weight_grad": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "tgru_head_grad_floats": (ctypes.c_size_t, [_i] * 3),
     "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),
     "tgru_head_forward": (_i, [_vp] * 2 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp]),

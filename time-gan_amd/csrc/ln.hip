@@ -1,0 +1,167 @@
+// LayerNorm over the last dimension for rows of up to 128 floats (a multiple of 4), forward and
+// backward: the normalisations of the dense heads around the GRU (outdated_files/TimeGANv1.py:45,67)
+// at hidden sizes beyond what the fused head kernels of head.hip cover (e.g. H = 96).
+//
+// HBM-bound by construction: forward reads x and writes y once (plus mean / rstd per row), backward reads
+// x and dy once and writes dx once.  Half a wave (32 lanes x 4 consecutive floats) owns a row, the row
+// sums are five butterfly exchanges inside the half; a lane keeps the same four columns for every row it
+// visits, so the column sums for d(gamma) / d(beta) accumulate in registers, are combined over the
+// workgroup's eight row slots through LDS and leave ONE partial per workgroup; a second kernel sums
+// the partials in a fixed order (deterministic, no atomics).
+#include "tgru_internal.h"
+#include "../../include/tgru.h"
+
+namespace tgru {
+namespace ln {
+
+constexpr int kThreads = 256;
+constexpr int kRowsPerPass = kThreads / 32;   // 8 rows per workgroup and pass
+constexpr int kMaxWidth = 128;
+constexpr int kMaxWorkgroups = 1024;
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ y,
+                                                          float *__restrict__ stats, long rows, int W, float eps) {
+    const int c = (threadIdx.x & 31) * 4, slot = threadIdx.x >> 5;
+    const bool on = c < W;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = (on && gamma) ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b = (on && beta) ? *reinterpret_cast<const float4 *>(beta + c) : zero4;
+    const float inv = 1.f / (float)W;
+    for (long r0 = (long)blockIdx.x * kRowsPerPass; r0 < rows; r0 += (long)gridDim.x * kRowsPerPass) {
+        const long r = r0 + slot;
+        const long rc = r < rows ? r : rows - 1;       // rows past the end are computed on the last row, not stored
+        const int cc = on ? c : 0;
+        float4 v = *reinterpret_cast<const float4 *>(x + rc * W + cc);
+        if (!on) v = zero4;
+        const float mean = half_wave_sum(v.x + v.y + v.z + v.w) * inv;
+        const float4 d = on ? make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean) : zero4;
+        const float var = half_wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * inv;
+        const float rstd = rsqrtf(var + eps);
+        if (r < rows) {
+            if (on)
+                *reinterpret_cast<float4 *>(y + r * W + c) =
+                    make_float4(d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y, d.z * rstd * g.z + b.z, d.w * rstd * g.w + b.w);
+            if (c == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                          float *__restrict__ dx, float *__restrict__ part, long rows, int W) {
+    __shared__ float red[kRowsPerPass][2][kMaxWidth];
+    const int c = (threadIdx.x & 31) * 4, slot = threadIdx.x >> 5;
+    const bool on = c < W;
+    const int cc = on ? c : 0;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = (on && gamma) ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float inv = 1.f / (float)W;
+    float4 sg = zero4, sb = zero4;     // column sums of dy * xhat and of dy over this lane's rows
+    for (long r0 = (long)blockIdx.x * kRowsPerPass; r0 < rows; r0 += (long)gridDim.x * kRowsPerPass) {
+        const long r = r0 + slot;
+        const bool live = r < rows;
+        const long rc = live ? r : rows - 1;
+        float4 v = *reinterpret_cast<const float4 *>(x + rc * W + cc);
+        float4 d = *reinterpret_cast<const float4 *>(dy + rc * W + cc);
+        const float mean = stats[2 * rc], rstd = stats[2 * rc + 1];
+        if (!on || !live) { v = make_float4(mean, mean, mean, mean); d = zero4; }
+        const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+        const float4 gd = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        const float m1 = half_wave_sum(gd.x + gd.y + gd.z + gd.w) * inv;
+        const float m2 = half_wave_sum(gd.x * xh.x + gd.y * xh.y + gd.z * xh.z + gd.w * xh.w) * inv;
+        if (live && on && dx)
+            *reinterpret_cast<float4 *>(dx + r * W + c) =
+                make_float4(rstd * (gd.x - m1 - xh.x * m2), rstd * (gd.y - m1 - xh.y * m2),
+                            rstd * (gd.z - m1 - xh.z * m2), rstd * (gd.w - m1 - xh.w * m2));
+        sg.x += d.x * xh.x; sg.y += d.y * xh.y; sg.z += d.z * xh.z; sg.w += d.w * xh.w;
+        sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    }
+    if (on) {
+        *reinterpret_cast<float4 *>(&red[slot][0][c]) = sg;
+        *reinterpret_cast<float4 *>(&red[slot][1][c]) = sb;
+    }
+    __syncthreads();
+    // one partial per workgroup: part[blockIdx][2][W], the eight row slots added in order
+    for (int i = threadIdx.x; i < 2 * W; i += kThreads) {
+        const int which = i / W, col = i - which * W;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRowsPerPass; ++k) s += red[k][which][col];
+        part[(long)blockIdx.x * 2 * W + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nparts, int W,
+                                                                 float *dgamma, float *dbeta, int accumulate) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= 2 * W) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nparts; k += 4) {
+        s0 += part[(long)k * 2 * W + i];
+        s1 += part[(long)(k + 1) * 2 * W + i];
+        s2 += part[(long)(k + 2) * 2 * W + i];
+        s3 += part[(long)(k + 3) * 2 * W + i];
+    }
+    for (; k < nparts; ++k) s0 += part[(long)k * 2 * W + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    float *dst = i < W ? dgamma : dbeta;
+    const int col = i < W ? i : i - W;
+    if (dst) dst[col] = accumulate ? dst[col] + s : s;
+}
+
+static int workgroups(long rows) {
+    const long n = (rows + kRowsPerPass - 1) / kRowsPerPass;
+    return (int)(n < kMaxWorkgroups ? n : kMaxWorkgroups);
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace ln
+}  // namespace tgru
+
+using namespace tgru;
+
+extern "C" {
+
+int tgru_layer_norm_supported(int width) { return width >= 4 && width <= ln::kMaxWidth && (width & 3) == 0; }
+
+size_t tgru_layer_norm_backward_workspace_bytes(long rows, int width) {
+    if (rows <= 0 || !tgru_layer_norm_supported(width)) return 0;
+    return (size_t)ln::workgroups(rows) * 2 * width * sizeof(float);
+}
+
+int tgru_layer_norm_forward(const float *x, const float *gamma, const float *beta, float *y, float *stats, long rows,
+                            int width, float eps, tgru_stream_t stream) {
+    if (rows <= 0 || !tgru_layer_norm_supported(width)) return TGRU_E_DIMS;
+    if (!x || !y || !stats) return TGRU_E_NULL;
+    if (!ln::aligned16(x) || !ln::aligned16(y) || (gamma && !ln::aligned16(gamma)) || (beta && !ln::aligned16(beta)))
+        return TGRU_E_ALIGN;
+    hipLaunchKernelGGL(ln::ln_fwd_kernel, dim3(ln::workgroups(rows)), dim3(ln::kThreads), 0, (hipStream_t)stream, x, gamma,
+                       beta, y, stats, rows, width, eps);
+    return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+}
+
+int tgru_layer_norm_backward(const float *x, const float *dy, const float *stats, const float *gamma, float *dx,
+                             float *dgamma, float *dbeta, float *workspace, long rows, int width, int accumulate,
+                             tgru_stream_t stream) {
+    if (rows <= 0 || !tgru_layer_norm_supported(width) || (accumulate != 0 && accumulate != 1)) return TGRU_E_DIMS;
+    if (!x || !dy || !stats || !workspace) return TGRU_E_NULL;
+    if (!ln::aligned16(x) || !ln::aligned16(dy) || (dx && !ln::aligned16(dx)) || (gamma && !ln::aligned16(gamma)))
+        return TGRU_E_ALIGN;
+    const int nwg = ln::workgroups(rows);
+    hipLaunchKernelGGL(ln::ln_bwd_kernel, dim3(nwg), dim3(ln::kThreads), 0, (hipStream_t)stream, x, dy, stats, gamma, dx,
+                       workspace, rows, width);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(ln::ln_bwd_reduce_kernel, dim3((2 * width + ln::kThreads - 1) / ln::kThreads),
+                           dim3(ln::kThreads), 0, (hipStream_t)stream, workspace, nwg, width, dgamma, dbeta, accumulate);
+    return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
+}
+
+}  // extern "C"

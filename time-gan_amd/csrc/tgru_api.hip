@@ -205,6 +205,31 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
     return TGRU_OK;
 }
 
+size_t tgru_linear_weight_grad_workspace_bytes(int rows, int out_f, int in_f) {
+    if (rows <= 0 || out_f <= 0 || in_f <= 0) return 0;
+    int kc;
+    const int ns = split_for(out_f, in_f, rows, &kc);
+    return (size_t)ns * out_f * in_f * sizeof(float);
+}
+
+int tgru_linear_weight_grad(const float *dy, const float *x, float *dw, float *workspace, int rows, int out_f,
+                            int in_f, int accumulate, tgru_stream_t stream) {
+    if (rows <= 0 || out_f <= 0 || in_f <= 0) return TGRU_E_DIMS;
+    if (!dy || !x || !dw || !workspace) return TGRU_E_NULL;
+    if (accumulate != 0 && accumulate != 1) return TGRU_E_DIMS;
+    int kc;
+    const int ns = split_for(out_f, in_f, rows, &kc);
+    GemmArgs g{};
+    g.A = dy; g.lda = out_f; g.Bm = x; g.ldb = in_f; g.C = workspace; g.ldc = in_f; g.bias = nullptr;
+    g.M = out_f; g.N = in_f; g.K = rows; g.kchunk = kc; g.slab_stride = (long)out_f * in_f; g.accumulate = 0;
+    g.amap = RowMap{0, 1, 1, nullptr};
+    g.bmap = g.amap;
+    g.cmap = g.amap;
+    TGRU_HIP(launch_gemm(g, false, false, ns, (hipStream_t)stream));
+    TGRU_HIP(launch_slab_reduce(workspace, g.slab_stride, ns, dw, (long)out_f * in_f, accumulate, (hipStream_t)stream));
+    return TGRU_OK;
+}
+
 static int check_forward(const tgru_forward_args &c) {
     int rc = check_dims(c.B, c.T, c.In, c.H, c.L, c.layout);
     if (rc != TGRU_OK) return rc;

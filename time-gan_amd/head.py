@@ -102,8 +102,8 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
     kernels do not cover the widths (still on the GPU)."""
     assert (ln1 is None) == (lin2 is None)
     if not supported(x, lin1, lin2):
-        h = lin1(x if ln0 is None else ln0(x))
-        return h if lin2 is None else lin2(torch.relu(ln1(h)))
+        h = wide_linear(x if ln0 is None else wide_layer_norm(x, ln0), lin1)
+        return h if lin2 is None else wide_linear(torch.relu(wide_layer_norm(h, ln1)), lin2)
     eps = (ln0 or ln1).eps if (ln0 is not None or ln1 is not None) else 1e-5
     if ln0 is not None and ln1 is not None:
         assert ln0.eps == ln1.eps
@@ -112,6 +112,100 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
                                lin1.weight, lin1.bias,
                                None if ln1 is None else ln1.weight, None if ln1 is None else ln1.bias,
                                None if lin2 is None else lin2.weight, None if lin2 is None else lin2.bias)
+
+
+class _WideLinearFunction(torch.autograd.Function):
+    """y = x W^T + b for heads wider than the fused kernels cover.  Forward and dx are torch's GEMMs; the
+    weight gradient dy^T x, a (out x in) product over B*T rows, goes through tgru_linear_weight_grad, which
+    splits it over the rows (the vendor GEMM picks an unsplit 32 x 32 tiling for it: 9 workgroups)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()
+            rows, out_f, in_f = dy2.shape[0], w.shape[0], w.shape[1]
+            dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+            lb = lib()
+            ws = torch.empty(max(1, lb.tgru_linear_weight_grad_workspace_bytes(rows, out_f, in_f) // 4),
+                             device=x.device, dtype=torch.float32)
+            with on_device(x.device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+                check(lb.tgru_linear_weight_grad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(ws), rows, out_f, in_f, 0, stream),
+                      "tgru_linear_weight_grad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+class _WideLayerNormFunction(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (width a multiple of 4, at most 128) on tgru_layer_norm_forward /
+    tgru_layer_norm_backward: each tensor crosses HBM once per pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = torch.empty_like(x2)
+        stats = torch.empty(2 * x2.shape[0], device=x.device, dtype=torch.float32)
+        with on_device(x.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            check(lib().tgru_layer_norm_forward(_ptr(x2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), x2.shape[0],
+                                                x2.shape[1], float(eps), stream), "tgru_layer_norm_forward")
+        ctx.save_for_backward(x2, stats, gamma)
+        ctx.has_beta = beta is not None
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats, gamma = ctx.saved_tensors
+        rows, width = x2.shape
+        dy2 = dy.reshape(rows, width).contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
+        dbeta = torch.empty(width, device=x2.device, dtype=torch.float32) if (ctx.has_beta and ctx.needs_input_grad[2]) else None
+        lb = lib()
+        ws = torch.empty(max(1, lb.tgru_layer_norm_backward_workspace_bytes(rows, width) // 4), device=x2.device,
+                         dtype=torch.float32)
+        with on_device(x2.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+            check(lb.tgru_layer_norm_backward(_ptr(x2), _ptr(dy2), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dgamma),
+                                              _ptr(dbeta), _ptr(ws), rows, width, 0, stream), "tgru_layer_norm_backward")
+        return (None if dx is None else dx.view(ctx.shape)), dgamma, dbeta, None
+
+
+WIDE_LINEAR_MIN_ROWS = 2048
+
+
+def wide_layer_norm(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
+    """ln(x); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on and for widths the library covers, through the
+    library's LayerNorm kernels."""
+    width = x.shape[-1]
+    rows = x.numel() // max(1, width)
+    if (x.is_cuda and x.dtype == torch.float32 and rows >= WIDE_LINEAR_MIN_ROWS and len(ln.normalized_shape) == 1
+            and ln.normalized_shape[0] == width and lib().tgru_layer_norm_supported(width)
+            and (ln.weight is None or ln.weight.dtype == torch.float32)):
+        return _WideLayerNormFunction.apply(x, ln.weight, ln.bias, ln.eps)
+    return ln(x)
+
+
+def wide_linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+    """lin(x); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on, with the row-split weight gradient."""
+    rows = x.numel() // max(1, x.shape[-1])
+    if (x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32 and rows >= WIDE_LINEAR_MIN_ROWS
+            and torch.is_grad_enabled() and lin.weight.requires_grad):
+        return _WideLinearFunction.apply(x, lin.weight, lin.bias)
+    return lin(x)
 
 
 def _split_grads(dparams, din, dmid, dout, params):
