@@ -17,7 +17,7 @@ namespace ln {
 constexpr int kThreads = 256;
 constexpr int kRowsPerPass = kThreads / 32;   // 8 rows per workgroup and pass
 constexpr int kMaxWidth = 128;
-constexpr int kMaxWorkgroups = 1024;
+constexpr int kMaxWorkgroups = 256;     // one per CU; also the number of partial column sums
 
 __device__ __forceinline__ float half_wave_sum(float v) {
     v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
@@ -97,20 +97,33 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float *__restric
     }
 }
 
+// dgamma / dbeta = column sums of the per-workgroup partials part[nparts][2][W].  Workgroup = 32 columns x
+// 8 groups of partials; a group adds a contiguous range with four interleaved accumulators, the groups
+// are combined in fixed order.
 __global__ __launch_bounds__(kThreads) void ln_bwd_reduce_kernel(const float *__restrict__ part, int nparts, int W,
                                                                  float *dgamma, float *dbeta, int accumulate) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= 2 * W) return;
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    const int per = (nparts + 7) / 8;
+    const int k0 = grp * per, k1 = min(nparts, k0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nparts; k += 4) {
-        s0 += part[(long)k * 2 * W + i];
-        s1 += part[(long)(k + 1) * 2 * W + i];
-        s2 += part[(long)(k + 2) * 2 * W + i];
-        s3 += part[(long)(k + 3) * 2 * W + i];
+    if (i < 2 * W) {
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            s0 += part[(long)k * 2 * W + i];
+            s1 += part[(long)(k + 1) * 2 * W + i];
+            s2 += part[(long)(k + 2) * 2 * W + i];
+            s3 += part[(long)(k + 3) * 2 * W + i];
+        }
+        for (; k < k1; ++k) s0 += part[(long)k * 2 * W + i];
     }
-    for (; k < nparts; ++k) s0 += part[(long)k * 2 * W + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    red[grp][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp != 0 || i >= 2 * W) return;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][c];
     float *dst = i < W ? dgamma : dbeta;
     const int col = i < W ? i : i - W;
     if (dst) dst[col] = accumulate ? dst[col] + s : s;
@@ -159,7 +172,7 @@ int tgru_layer_norm_backward(const float *x, const float *dy, const float *stats
     hipLaunchKernelGGL(ln::ln_bwd_kernel, dim3(nwg), dim3(ln::kThreads), 0, (hipStream_t)stream, x, dy, stats, gamma, dx,
                        workspace, rows, width);
     if (dgamma || dbeta)
-        hipLaunchKernelGGL(ln::ln_bwd_reduce_kernel, dim3((2 * width + ln::kThreads - 1) / ln::kThreads),
+        hipLaunchKernelGGL(ln::ln_bwd_reduce_kernel, dim3((2 * width + 31) / 32),
                            dim3(ln::kThreads), 0, (hipStream_t)stream, workspace, nwg, width, dgamma, dbeta, accumulate);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
