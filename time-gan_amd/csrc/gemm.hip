@@ -341,8 +341,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *slabs, lo
                                                           float *out, long n, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float v = 0.f;
-    for (int z = 0; z < nslabs; ++z) v += slabs[(long)z * stride + i];
+    // four interleaved partial sums (fixed order): four loads in flight instead of one
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int z = 0;
+    for (; z + 3 < nslabs; z += 4) {
+        v0 += slabs[(long)z * stride + i];
+        v1 += slabs[(long)(z + 1) * stride + i];
+        v2 += slabs[(long)(z + 2) * stride + i];
+        v3 += slabs[(long)(z + 3) * stride + i];
+    }
+    for (; z < nslabs; ++z) v0 += slabs[(long)z * stride + i];
+    float v = (v0 + v1) + (v2 + v3);
     if (accumulate) v += out[i];
     out[i] = v;
 }
