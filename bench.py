@@ -130,8 +130,21 @@ def device_barrier(dist, dev):
     on the same device queue (a host-side barrier is not, with backends that run device-tensor
     collectives asynchronously), then drained."""
     t = torch.zeros(1, device=dev)
-    dist.all_reduce(t)
+    bucket_all_reduce(dist, t)
     torch.cuda.synchronize()
+
+
+def bucket_all_reduce(dist, t):
+    """SUM over ranks, in place.  RCCL takes the device tensor as it is.  With the gloo backend (CPU
+    rehearsals of the multi-rank flow, several ranks sharing one GPU) the tensor is staged through the host:
+    gloo's own handling of device tensors stalls when the ranks' kernels queue up on one GPU."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        torch.cuda.synchronize()
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t)
 
 
 def dp_graph_child():
@@ -167,9 +180,9 @@ def child_graph_probe(backend, rank, world, joint):
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29541")) + 17))
     cmd = [sys.executable, "-u", os.path.abspath(__file__), "--backend", backend]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=90)
     except subprocess.TimeoutExpired:
-        joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish in 150 s"
+        joint["hipgraph_note"] = "graph-mode data-parallel probe did not finish in 90 s"
         return
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DPGRAPH ")]
     if r.returncode == 0 and lines:
@@ -235,7 +248,7 @@ def main():
         runner.forward(x)
         runner.backward(dy)
         if do_ar:
-            dist.all_reduce(runner.flat_grads)
+            bucket_all_reduce(dist, runner.flat_grads)
 
     for _ in range(args.warmup):
         step()
@@ -273,14 +286,14 @@ def main():
         if i % grp == grp - 1:
             ev1[i // grp].record()
         if do_ar:
-            dist.all_reduce(runner.flat_grads)
+            bucket_all_reduce(dist, runner.flat_grads)
     torch.cuda.synchronize()
     if dist:
         device_barrier(dist, dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     dev_ms = sorted(a.elapsed_time(b) / grp for a, b in zip(ev0, ev1))
@@ -362,7 +375,7 @@ def main():
         sys.stdout.flush()
         os._exit(0)
 
-    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "420")) + (0 if rank == 0 else 5), give_up)
+    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "150")) + (0 if rank == 0 else 5), give_up)
     watchdog.daemon = True
     watchdog.start()
 
@@ -373,7 +386,9 @@ def main():
             out["timegan_training"] = joint
         group = dist.group.WORLD if multi else None
         joint_training_probe(tg, dev, 6, H, L, T, B, group, False, joint)
-        if multi:
+        if multi and args.backend != "nccl":
+            joint["hipgraph_note"] = "graph mode with collectives inside needs the RCCL backend"
+        elif multi:
             child_graph_probe(args.backend, rank, world, joint)
         else:
             joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
