@@ -155,3 +155,42 @@ def test_sharded_generation_and_scores_match_single_process(tmp_path):
     np.testing.assert_allclose(got["x"].numpy(), x.numpy(), rtol=1e-5, atol=1e-6)
     assert abs(got["d"] - d) <= 1e-6            # accuracies are ratios of small integers
     assert abs(got["p"] - p) <= 1e-4 * abs(p) + 1e-6
+
+
+def _fit_small(group=None):
+    """fit() over a small resident dataset whose last global batch is ragged (11 windows, batches of 4)."""
+    import timegan_amd as tg
+    tr = _make_trainer(group)
+    tr.cfg["system"]["batch_size"] = 4
+    data = np.random.default_rng(4).uniform(0, 1, (11, 8, 5)).astype(np.float32)
+    ds = tg.data.ResidentDataset(data, "cpu")
+    hist = tr.fit(ds, phases=("embedding", "supervisor"), seed=6)
+    return hist, tr.state_dicts()
+
+
+def _fit_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    hist, sd = _fit_small(dist.group.WORLD)
+    if rank == 0:
+        torch.save({"hist": hist, "sd": sd}, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_over_a_sharded_dataset_matches_single_process(tmp_path):
+    """Every rank takes its shard of each global batch (ragged tail included) and runs the same number of
+    steps; losses and parameters follow the single-process run on the whole batches."""
+    torch.set_num_threads(1)
+    ref_hist, ref_sd = _fit_small()
+    path = str(tmp_path / "fit.pt")
+    mp.spawn(_fit_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = torch.load(path, weights_only=False)
+    for phase in ("embedding", "supervisor"):
+        assert len(got["hist"][phase]) == len(ref_hist[phase]) == 3
+        np.testing.assert_allclose(got["hist"][phase], ref_hist[phase], rtol=2e-3)
+    for net in ("emb", "rec", "sup"):
+        for name, p in ref_sd[net].items():
+            np.testing.assert_allclose(got["sd"][net][name].numpy(), p.numpy(), rtol=5e-3, atol=5e-4, err_msg=f"{net}.{name}")
