@@ -11,7 +11,9 @@ Rank 0 prints ONE JSON line.  `value` is sequences/s over all ranks.  `roofline`
 step (all kernels of forward + backward, timed with HIP events on the launch stream) against the
 bound of the workload: HBM bytes for H=24, fp32 MFMA FLOPs for H>=96.  `cpu_baseline` times the
 operator the reference itself calls (torch.nn.GRU on CPU behind pack_padded_sequence) on the host
-cores of the same box, on a bounded number of steps of the same workload.
+cores of the same box, on a bounded number of steps of the same workload.  The secondary training
+probe (`timegan_training`) runs after the headline measurement under a deadline (TGRU_BENCH_DEADLINE,
+150 s): if it stalls, the line is printed with what has been measured.
 """
 import argparse
 import json
