@@ -1,25 +1,42 @@
 """Benchmark of the GRU forward + BPTT hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4] [--only]
+                    [--no-cpu] [--no-training]
 
 A step is one forward + full backward (dx and all weight gradients) of one 3-layer GRU stack over one
 batch of synthetic input already resident in HBM, issued through the C ABI (libtgru.so).  With N > 1
 every rank owns a batch shard of the same size (weak scaling) and the step ends with one RCCL
 all-reduce of the flat weight-gradient bucket, as data-parallel training needs.
 
-Rank 0 prints ONE JSON line.  `value` is sequences/s over all ranks.  `roofline` prices the whole
-step (all kernels of forward + backward, timed with HIP events on the launch stream) against the
-bound of the workload: HBM bytes for H=24, fp32 MFMA FLOPs for H>=96.  `cpu_baseline` times the
-operator the reference itself calls (torch.nn.GRU on CPU behind pack_padded_sequence) on the host
-cores of the same box, on a bounded number of steps of the same workload.  The secondary training
-probe (`timegan_training`) runs after the headline measurement under a deadline (TGRU_BENCH_DEADLINE,
-150 s): if it stalls, the line is printed with what has been measured.
+Rank 0 prints ONE JSON line.  The headline (`value`, `ms_per_step`, `config`, `roofline`, `cpu_baseline`,
+`launches_per_step`) is the workload named by --workload (default c4: the per-GPU shard of the stress
+configuration, the largest single-GPU configuration), timed for EXACTLY --steps steps after --warmup
+warm-up steps between barrier + synchronize brackets.  Unless --only is given, `workloads` carries the
+same record for each of c2 / c3 / c4 (the other two with step counts of their own), and
+`timegan_training` the iterations per second of the three training phases on the HIP path at the c2 and c3
+dimensions, next to the same trainer on torch's CPU nn.GRU at the c1 dimensions.
+
+`value` is sequences/s over all ranks.  `roofline` prices the whole step (all kernels of forward +
+backward, timed with HIP events on the launch stream) against the bound of the workload: HBM bytes for
+H = 24, fp32 MFMA FLOPs for H >= 96.  `cpu_baseline` times the operator the reference itself calls
+(torch.nn.GRU on CPU behind pack_padded_sequence) on the host cores of the same box, on a bounded sample of
+the same workload, median of five steps per thread count; CPU model and core counts are stated.
+If anything after the headline measurement stalls past TGRU_BENCH_DEADLINE seconds (default 400), rank 0
+prints the line with what has been measured and `"stalled": true`, and every rank exits with status 3.
 """
+import os
+
+try:                                    # CPUs this process may use, read before OpenMP binds the main thread
+    USABLE_CPUS = len(os.sched_getaffinity(0))
+except AttributeError:
+    USABLE_CPUS = os.cpu_count() or 1
+os.environ.setdefault("OMP_PROC_BIND", "close")     # CPU legs: keep OpenMP threads on neighbouring cores
+
 import argparse
 import json
-import os
-import sys
+import statistics
 import subprocess
+import sys
 import time
 
 import torch
@@ -33,6 +50,10 @@ WORKLOADS = {
     "c3": (1024, 24, 96, 96, 3, "energy config: GRU stack fwd+bwd, B1024 T24 H96 L3"),
     "c4": (2048, 256, 512, 512, 3, "stress config: GRU stack fwd+bwd, per-GPU shard B2048 T256 H512 L3"),
 }
+# (steps, warmup) of a workload when it is not the headline
+SUB_STEPS = {"c2": (200, 20), "c3": (100, 10), "c4": (10, 2)}
+# features of the training probes at the workloads' dimensions (stock: 6, energy: 28)
+TRAIN_FEATURES = {"c2": 6, "c3": 28}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
 
@@ -60,71 +81,125 @@ def make_weights(In, H, L, device, seed):
     return ws
 
 
-def cpu_baseline(B, T, In, H, L, budget_s=20.0):
-    """torch.nn.GRU CPU fwd+bwd through pack/pad, as the reference calls it."""
+def host_cpu():
+    """CPU model, physical / logical core counts of the machine and the cores this process may use."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    usable = USABLE_CPUS
+    return {"model": model, "physical_cores": len(phys) or None, "logical_cpus": logical or (os.cpu_count() or 1),
+            "usable_cpus": usable}
+
+
+def cpu_thread_counts():
+    """1 thread and the CPU share of a one-GPU box (16), bounded by what this process may use."""
+    many = max(1, min(16, USABLE_CPUS))
+    return [1] if many == 1 else [1, many]
+
+
+def cpu_baseline(B, T, In, H, L, repeats=5):
+    """torch.nn.GRU CPU fwd+bwd through pack/pad, as the reference calls it: median of `repeats` steps per
+    thread count on a bounded sample of the workload (the stress shape: 32 sequences x the first 32 of the
+    256 steps, the result scaled to full-length sequences -- the work is linear in T)."""
     import torch.nn as nn
     results = []
-    for threads in (1, min(16, os.cpu_count() or 1)):
+    heavy = B * T * H > 1024 * 24 * 96
+    Bc, Tc = (32, 32) if heavy else (B, T)
+    for threads in cpu_thread_counts():
         torch.set_num_threads(threads)
         torch.manual_seed(42)
         gru = nn.GRU(In, H, L, batch_first=True)
-        Bc = B if B * T * H <= 1024 * 24 * 96 else 256     # bounded sample for the stress shape
-        x = torch.rand(Bc, T, In, requires_grad=True)
-        lens = [T] * Bc
+        x = torch.rand(Bc, Tc, In, requires_grad=True)
+        lens = [Tc] * Bc
 
         def step():
             gru.zero_grad()
             p = nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=True)
             o, _ = gru(p)
-            y, _ = nn.utils.rnn.pad_packed_sequence(o, batch_first=True, padding_value=0, total_length=T)
+            y, _ = nn.utils.rnn.pad_packed_sequence(o, batch_first=True, padding_value=0, total_length=Tc)
             y.sum().backward()
-        step()
-        n, t0 = 0, time.perf_counter()
-        while True:
+        for _ in range(2 if not heavy else 1):
             step()
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 200:
-                break
-        results.append({"threads": threads, "seqs_per_s": Bc * n / el, "steps": n, "batch": Bc})
-        if threads == (os.cpu_count() or 1):
-            break
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        med = statistics.median(ts)
+        results.append({"threads": threads, "seqs_per_s": Bc * (Tc / T) / med, "median_s": med})
     best = max(results, key=lambda r: r["seqs_per_s"])
+    cpu = host_cpu()
     return {"value": round(best["seqs_per_s"], 2), "unit": "seqs/s", "cores": best["threads"],
-            "kind": "reference",
+            "kind": "reference", "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"],
+            "logical_cpus": cpu["logical_cpus"], "usable_cpus": cpu["usable_cpus"],
             "sample": (f"torch {torch.__version__} CPU nn.GRU (the operator the reference calls) behind "
-                       f"pack_padded_sequence/pad_packed_sequence, fwd+bwd, batch {best['batch']} x {best['steps']} "
-                       f"steps of the same T/H/L; all thread counts tried: "
-                       + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}" for r in results))}
+                       f"pack_padded_sequence/pad_packed_sequence, fwd+bwd, {Bc} sequences x {Tc} of {T} steps, "
+                       f"same H/L, median of {repeats} steps after warm-up, OMP_PROC_BIND=close"
+                       + (", scaled to full-length sequences" if Tc != T else "") + "; thread counts tried: "
+                       + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}/s" for r in results))}
 
 
-def joint_training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3):
-    """Secondary figure: 3-phase TimeGAN steps on the HIP GRU (TimeGANv1.py:573-812 loop bodies).
+def training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3, rnn_cls=None):
+    """Secondary figure: 3-phase TimeGAN steps (TimeGANv1.py:573-812 loop bodies).
     One joint iteration = 10 x (generator step + embedder step) + 1 discriminator step
     = 116 GRU-stack forwards + 103 backwards plus the heads / losses / Adam work around them.
-    Measured eagerly and (`graphs`) with each optimiser sub-step replayed as a HIP graph; with a
+    Measured eagerly and (`graphs`) with each phase's step replayed as a HIP graph; with a
     process group the graphs contain the RCCL all-reduces.  Fills `out` key by key, so what has been
-    measured survives if a later part does not finish."""
+    measured survives if a later part does not finish.  `rnn_cls` (CPU leg): the recurrent module class,
+    torch.nn.GRU for the reference's own operator."""
     cfg = tg.make_cfg(features=features, hidden=H, layers=L, seq_len=T, device=str(dev))
     x = torch.rand(B, T, features, device=dev)
     prefix = "hipgraph_" if graphs else ""
     torch.manual_seed(42)
-    tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs)
+    kw = {} if rnn_cls is None else {"rnn_cls": rnn_cls}
+    tr = tg.TimeGANTrainer(cfg, device=dev, group=group, use_graphs=graphs, **kw)
     if graphs and not tr.use_graphs:
         out["hipgraph_note"] = "graph mode not available with this backend"
         return
-    short = group is not None and not graphs      # eager data-parallel probe: launch-bound, keep it short
+    on_gpu = dev.type == "cuda"
+    short = (group is not None and not graphs) or not on_gpu     # launch-bound or CPU-bound: keep it short
     for name, fn, n in (("embedding", tr.embedding_step, 10 if short else 20),
                         ("supervisor", tr.supervisor_step, 10 if short else 20),
                         ("joint", tr.joint_step, 2 if short else iters * (4 if graphs else 1))):
-        for _ in range(3):
+        for _ in range(3 if on_gpu else 1):
             fn(x)
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        n0 = tg.launch_count() if on_gpu else 0
         t0 = time.perf_counter()
         for _ in range(n):
             fn(x)
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         out[f"{prefix}{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
+        if on_gpu and not graphs:
+            # the library's own launches (GRU, heads, losses, reductions, Adam); torch's elementwise kernels
+            # around them are not counted here (the rocprof kernel trace under profiles/ has the total)
+            out[f"{name}_tgru_launches_per_iter"] = round((tg.launch_count() - n0) / n, 1)
+
+
+def cpu_training_baseline(tg, out):
+    """The same trainer (modules, losses, optimiser stepping) on the CPU with torch.nn.GRU as its recurrent
+    module -- the reference's own path (TimeGANv1.py:573-812) -- at the sine config (5 features, H 24, 3 layers,
+    T 24, batch 128)."""
+    import torch.nn as nn
+    threads = cpu_thread_counts()[-1]
+    torch.set_num_threads(threads)
+    rec = {"note": f"build's trainer on torch CPU nn.GRU, sine config F5 H24 L3 T24 B128, {threads} threads"}
+    out["cpu_c1"] = rec
+    training_probe(tg, torch.device("cpu"), 5, 24, 3, 24, 128, None, False, rec, rnn_cls=nn.GRU)
 
 
 def device_barrier(dist, dev):
@@ -163,7 +238,7 @@ def dp_graph_child():
     import timegan_amd as tg
     B, T, _, H, L, _ = WORKLOADS["c2"]
     out = {}
-    joint_training_probe(tg, dev, 6, H, L, T, B, dist.group.WORLD, True, out)
+    training_probe(tg, dev, TRAIN_FEATURES["c2"], H, L, T, B, dist.group.WORLD, True, out)
     device_barrier(dist, dev)
     print("DPGRAPH " + json.dumps(out), flush=True)
     dist.destroy_process_group()
@@ -194,20 +269,145 @@ def child_graph_probe(backend, rank, world, joint):
                                   % (r.returncode, r.stderr.strip()[-200:]))
 
 
+def measure_workload(tg, name, steps, warmup, dev, dist, rank, world, do_ar, use_graph=False):
+    """Times `steps` steps of workload `name` after `warmup` warm-up steps.  Returns the record of the
+    workload on rank 0 (None elsewhere): value, ms_per_step, roofline, launches_per_step."""
+    B, T, In, H, L, desc = WORKLOADS[name]
+    torch.manual_seed(42 + rank)
+    weights = make_weights(In, H, L, dev, seed=42)           # replicated parameters
+    x = torch.rand(T, B, In, device=dev)                      # U[0,1) like MinMax-scaled data
+    dy = torch.randn(T, B, H, device=dev)
+    runner = tg.GRURunner(B, T, In, H, L, tg.LAYOUT_TBF, dev)
+    runner.set_weights(weights)
+
+    for _ in range(warmup):
+        runner.forward(x)
+        runner.backward(dy)
+        if do_ar:
+            bucket_all_reduce(dist, runner.flat_grads)
+    torch.cuda.synchronize()
+    n0 = tg.launch_count()
+    runner.forward(x)
+    n1 = tg.launch_count()
+    runner.backward(dy)
+    n2 = tg.launch_count()
+    launches = {"forward": n1 - n0, "backward": n2 - n1, "total": n2 - n0}
+    torch.cuda.synchronize()
+    # Optionally the step's launches are captured once into a HIP graph and the timed loop replays it; the
+    # all-reduce of the data-parallel case stays outside the graph.
+    graph = None
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            runner.forward(x)
+            runner.backward(dy)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+    if dist:
+        device_barrier(dist, dev)
+    torch.cuda.synchronize()
+    # HIP events bracket GROUPS of steps (an event record costs about as much as a launch): device time per
+    # step = group time / group size, gaps between the step's kernels and between steps included (and, with
+    # several ranks, the gradient all-reduce that ends each step)
+    grp = 10 if steps % 10 == 0 and H < 512 else 1
+    ngrp = steps // grp
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i % grp == 0:
+            ev0[i // grp].record()
+        if graph is not None:
+            graph.replay()
+        else:
+            runner.forward(x)
+            runner.backward(dy)
+        if i % grp == grp - 1:
+            ev1[i // grp].record()
+        if do_ar:
+            bucket_all_reduce(dist, runner.flat_grads)
+    torch.cuda.synchronize()
+    if dist:
+        device_barrier(dist, dev)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    dev_ms = sorted(a.elapsed_time(b) / grp for a, b in zip(ev0, ev1))
+    dev_ms_avg = sum(dev_ms) / len(dev_ms)
+    # the two halves of a step, timed apart in a short untimed pass of host-issued launches
+    nh = min(steps, 50)
+    eh = [[torch.cuda.Event(enable_timing=True) for _ in range(nh)] for _ in range(3)]
+    for i in range(nh):
+        eh[0][i].record()
+        runner.forward(x)
+        eh[1][i].record()
+        runner.backward(dy)
+        eh[2][i].record()
+    torch.cuda.synchronize()
+    fwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[0], eh[1])) / nh
+    bwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[1], eh[2])) / nh
+    if rank != 0:
+        return None
+
+    flops, bytes_ = algorithmic_work(B, T, In, H, L)
+    value = world * B * steps / elapsed
+    if H < 64:
+        achieved = bytes_ / (dev_ms_avg * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None}
+    else:
+        achieved = flops / (dev_ms_avg * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None}
+    for tr_file in (os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{name}.json"),
+                    os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{name}.json")):
+        if os.path.exists(tr_file):     # HBM bytes per step from separate rocprofv3 --pmc passes of this command
+            with open(tr_file) as f:
+                roof["traffic"] = json.load(f)["hbm_bytes_per_step"]
+            roof["traffic_source"] = os.path.relpath(tr_file, ROOT)
+            break
+    roof["kernel"] = "whole step: every kernel of one stack forward+backward (HIP events around the step)"
+    roof["device_ms_per_step"] = round(dev_ms_avg, 4)
+    roof["device_ms_median"] = round(dev_ms[len(dev_ms) // 2], 4)
+    # the two halves of the step priced separately (forward kernel(s); backward + gradient reduce)
+    wbytes = sum(4.0 * (3 * H * (In if l == 0 else H) + 3 * H * H + 6 * H) for l in range(L))
+    fb = B * T * 4.0 * sum(6 * H for _ in range(L)) + wbytes            # x/y + 4 saved gate values
+    bb = bytes_ - fb
+    ff, bf = flops / 3.0, flops * 2.0 / 3.0
+    roof["parts"] = {
+        "forward": {"device_ms": round(fwd_ms_avg, 4), "GB/s": round(fb / fwd_ms_avg / 1e6, 2),
+                    "TFLOP/s": round(ff / fwd_ms_avg / 1e9, 3)},
+        "backward": {"device_ms": round(bwd_ms_avg, 4), "GB/s": round(bb / bwd_ms_avg / 1e6, 2),
+                     "TFLOP/s": round(bf / bwd_ms_avg / 1e9, 3)}}
+    roof["algorithmic_bytes_per_step"] = bytes_
+    roof["algorithmic_flops_per_step"] = flops
+    return {"value": round(value, 2), "unit": "seqs/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 4),
+            "config": {"workload": f"{name}: {desc}", "global_batch": world * B, "seq_len": T,
+                       "launch": "host-issued kernels" if graph is None else "one HIP graph replay per step",
+                       "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
+            "roofline": roof, "launches_per_step": launches}
+
+
 def main():
     if os.environ.get("TGRU_BENCH_CHILD") == "1":
         return dp_graph_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS), help="the headline workload")
+    ap.add_argument("--only", action="store_true", help="measure the headline workload only")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    ap.add_argument("--no-training", "--no-joint", dest="no_training", action="store_true",
+                    help="skip the secondary 3-phase training probes")
     ap.add_argument("--no-allreduce", action="store_true")
-    ap.add_argument("--no-joint", action="store_true", help="skip the secondary 3-phase training probe")
     ap.add_argument("--graph", action="store_true",
-                    help="replay one captured HIP graph per step instead of issuing its three launches from the host "
-                         "(measured slower here: 44.7 vs 41.3 us per step, the graph's inter-kernel gaps are larger)")
+                    help="replay one captured HIP graph per step instead of issuing its launches from the host")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the multi-rank code path (process group, all-reduces, graph capture of "
@@ -237,125 +437,15 @@ def main():
 
     import timegan_amd as tg
 
-    B, T, In, H, L, desc = WORKLOADS[args.workload]
-    torch.manual_seed(42 + rank)
-    weights = make_weights(In, H, L, dev, seed=42)           # replicated parameters
-    x = torch.rand(T, B, In, device=dev)                      # U[0,1) like MinMax-scaled data
-    dy = torch.randn(T, B, H, device=dev)
-    runner = tg.GRURunner(B, T, In, H, L, tg.LAYOUT_TBF, dev)
-    runner.set_weights(weights)
     do_ar = multi and not args.no_allreduce
-
-    def step():
-        runner.forward(x)
-        runner.backward(dy)
-        if do_ar:
-            bucket_all_reduce(dist, runner.flat_grads)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # Optionally the step's launches (forward, backward, gradient reduce) are captured once into a HIP graph
-    # and the timed loop replays it; the all-reduce of the data-parallel case stays outside the graph.
-    graph = None
-    if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            runner.forward(x)
-            runner.backward(dy)
-        for _ in range(3):
-            graph.replay()
-        torch.cuda.synchronize()
-    if dist:
-        device_barrier(dist, dev)
-    torch.cuda.synchronize()
-    # HIP events bracket GROUPS of steps (an event record costs about as much as a launch): device time per
-    # step = group time / group size, gaps between the step's kernels and between steps included (and, with
-    # several ranks, the gradient all-reduce that ends each step)
-    grp = 10 if args.steps % 10 == 0 else 1
-    ngrp = args.steps // grp
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(ngrp)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % grp == 0:
-            ev0[i // grp].record()
-        if graph is not None:
-            graph.replay()
-        else:
-            runner.forward(x)
-            runner.backward(dy)
-        if i % grp == grp - 1:
-            ev1[i // grp].record()
-        if do_ar:
-            bucket_all_reduce(dist, runner.flat_grads)
-    torch.cuda.synchronize()
-    if dist:
-        device_barrier(dist, dev)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    dev_ms = sorted(a.elapsed_time(b) / grp for a, b in zip(ev0, ev1))
-    dev_ms_avg = sum(dev_ms) / len(dev_ms)
-    # the two halves of a step, timed apart in a short untimed pass of host-issued launches
-    nh = min(args.steps, 50)
-    eh = [[torch.cuda.Event(enable_timing=True) for _ in range(nh)] for _ in range(3)]
-    for i in range(nh):
-        eh[0][i].record()
-        runner.forward(x)
-        eh[1][i].record()
-        runner.backward(dy)
-        eh[2][i].record()
-    torch.cuda.synchronize()
-    fwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[0], eh[1])) / nh
-    bwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[1], eh[2])) / nh
-
+    head = measure_workload(tg, args.workload, args.steps, args.warmup, dev, dist, rank, world, do_ar, args.graph)
     out = None
     if rank == 0:
-        flops, bytes_ = algorithmic_work(B, T, In, H, L)
-        value = world * B * args.steps / elapsed
-        if H < 64:
-            achieved = bytes_ / (dev_ms_avg * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None}
-        else:
-            achieved = flops / (dev_ms_avg * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None}
-        tr_file = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
-        if os.path.exists(tr_file):     # HBM bytes per step from separate rocprofv3 --pmc passes of this command
-            with open(tr_file) as f:
-                roof["traffic"] = json.load(f)["hbm_bytes_per_step"]
-            roof["traffic_source"] = os.path.relpath(tr_file, ROOT)
-        roof["kernel"] = "whole step: every kernel of one stack forward+backward (HIP events around the step)"
-        roof["device_ms_per_step"] = round(dev_ms_avg, 4)
-        roof["device_ms_median"] = round(dev_ms[len(dev_ms) // 2], 4)
-        # the two halves of the step priced separately (forward kernel(s); backward + gradient reduce)
-        wbytes = sum(4.0 * (3 * H * (In if l == 0 else H) + 3 * H * H + 6 * H) for l in range(L))
-        fb = B * T * 4.0 * sum(6 * H for _ in range(L)) + wbytes            # x/y + 4 saved gate values
-        bb = bytes_ - fb
-        ff, bf = flops / 3.0, flops * 2.0 / 3.0
-        roof["parts"] = {
-            "forward": {"device_ms": round(fwd_ms_avg, 4), "GB/s": round(fb / fwd_ms_avg / 1e6, 2),
-                        "TFLOP/s": round(ff / fwd_ms_avg / 1e9, 3)},
-            "backward": {"device_ms": round(bwd_ms_avg, 4), "GB/s": round(bb / bwd_ms_avg / 1e6, 2),
-                         "TFLOP/s": round(bf / bwd_ms_avg / 1e9, 3)}}
-        roof["algorithmic_bytes_per_step"] = bytes_
-        roof["algorithmic_flops_per_step"] = flops
-        out = {
-            "metric": "GRU stack fwd+bwd sequences/sec",
-            "value": round(value, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "global_batch": world * B, "seq_len": T,
-                       "launch": "host-issued kernels" if graph is None else "one HIP graph replay per step",
-                       "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
-            "roofline": roof,
-        }
+        out = {"metric": "GRU stack fwd+bwd sequences/sec", "value": head["value"], "unit": "seqs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
+               "launches_per_step": head["launches_per_step"], "workloads": {args.workload: head}}
 
     printed = []
 
@@ -365,37 +455,59 @@ def main():
             printed.append(True)
             print(json.dumps(out), flush=True)
 
-    # The secondary probes below run collectives that have only been rehearsed with one rank where this was
-    # written.  If one of them stalls, the headline result must still reach the driver: after the deadline
-    # rank 0 prints the line with what has been measured so far and every rank leaves.
+    # If anything below stalls (a wedged collective, a hung probe), the headline result still reaches the
+    # driver: after the deadline rank 0 prints the line with what has been measured so far, marked as
+    # stalled, and every rank leaves with a non-zero status -- a stall is a failed run.
     import threading
 
     def give_up():
         if rank == 0 and out is not None:
-            out.setdefault("timegan_training", {})["note_deadline"] = "secondary probes cut off at the deadline"
+            out["stalled"] = True
+            out["stalled_note"] = "cut off at the deadline; the figures present were measured before the stall"
         emit()
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
 
-    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "150")) + (0 if rank == 0 else 5), give_up)
+    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "400")) + (0 if rank == 0 else 5), give_up)
     watchdog.daemon = True
     watchdog.start()
 
-    if not args.no_joint and args.workload == "c2":
-        joint = {"note": "PyTorch autograd around the HIP GRU / head / loss kernels, batch %d per GPU, 6 features; "
-                         "the eager figures are host-launch bound at this size" % B}
+    if not args.only:
+        for name in sorted(WORKLOADS):
+            if name == args.workload:
+                continue
+            st, wu = SUB_STEPS[name]
+            rec = measure_workload(tg, name, st, wu, dev, dist, rank, world, do_ar)
+            if rank == 0:
+                out["workloads"][name] = rec
+
+    if not args.no_training and not args.only:
+        training = {"note": "PyTorch autograd around the HIP GRU / head / loss kernels; iterations per second of the "
+                            "embedding, supervisor and joint phases (one joint iteration = 10 x (G + E) + D "
+                            "sub-steps), eager and with each step replayed as one HIP graph"}
         if rank == 0:
-            out["timegan_training"] = joint
+            out["timegan_training"] = training
         group = dist.group.WORLD if multi else None
-        joint_training_probe(tg, dev, 6, H, L, T, B, group, False, joint)
-        if multi and args.backend != "nccl":
-            joint["hipgraph_note"] = "graph mode with collectives inside needs the RCCL backend"
-        elif multi:
-            child_graph_probe(args.backend, rank, world, joint)
-        else:
-            joint_training_probe(tg, dev, 6, H, L, T, B, group, True, joint)
+        for name in ("c2", "c3"):
+            B, T, _, H, L, _ = WORKLOADS[name]
+            rec = {"config": f"{TRAIN_FEATURES[name]} features, H {H}, L {L}, T {T}, batch {B} per GPU"}
+            training[name] = rec
+            training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, False, rec)
+            if multi and args.backend != "nccl":
+                rec["hipgraph_note"] = "graph mode with collectives inside needs the RCCL backend"
+            elif multi:
+                if name == "c2":
+                    child_graph_probe(args.backend, rank, world, rec)
+            else:
+                training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, True, rec)
+        if rank == 0 and world == 1 and not args.no_cpu:
+            cpu_training_baseline(tg, training)
+
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
+        for name, rec in out["workloads"].items():
+            B, T, In, H, L, _ = WORKLOADS[name]
+            rec["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
+        out["cpu_baseline"] = out["workloads"][args.workload]["cpu_baseline"]
     emit()
     if dist:
         device_barrier(dist, dev)

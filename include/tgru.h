@@ -59,6 +59,19 @@ enum {
 /* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */
 int tgru_version(void);
 
+/*
+ * Number of kernel launches the library has issued in this process so far (all entry points, all
+ * streams).  Read it before and after a step to learn the step's launch count.  No reference counterpart.
+ */
+unsigned long long tgru_launch_count(void);
+
+/*
+ * The library reads its kernel-family switches (environment variables TGRU_FORCE_GENERIC, TGRU_NO_VEC,
+ * TGRU_NO_MID, TGRU_NO_STEP; "1" selects the alternative kernels) once per process; this
+ * call reads them again.  No reference counterpart.
+ */
+void tgru_reload_switches(void);
+
 /* Text for a TGRU_E_* code.  No reference counterpart. */
 const char *tgru_error_string(int code);
 

@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _tgru_switches():
+    """The library caches its TGRU_* environment switches.  Tests that change them call
+    timegan_amd.reload_switches() after monkeypatch.setenv; this fixture (set up first, torn down last,
+    i.e. after monkeypatch has restored the environment) makes the library read the restored values."""
+    yield
+    lib_path = os.path.join(ROOT, "time-gan_amd", "libtgru.so")
+    if os.path.exists(lib_path):
+        import timegan_amd as tg
+        tg.reload_switches()

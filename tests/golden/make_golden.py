@@ -10,7 +10,8 @@ copied.  Two sources are used:
     pad_packed_sequence(total_length=T) behind, hx never passed
     (outdated_files/TimeGANv1.py:35-38,56-65).  fp32 outputs are the parity target, fp64 outputs
     the tie-breaker.
-  * module / loss / step level (modules_c1.npz, losses_c1.npz, steps_c1.npz): the reference's own
+  * module / loss / step level (modules_c1.npz, losses_c1.npz, steps_c1.npz; modules_c2.npz,
+    losses_c2.npz at the stock config's 6 features): the reference's own
     classes and functions, imported from --ref with `wandb` (a logging service that is not
     installed) and the plotting call stubbed out.
   * data level (scorer_split.npz): the reference's SineWave and Energy dataset classes on a seeded
@@ -146,12 +147,13 @@ def build_nets(R, cfg, seed):
             "g": R.Generator(cfg), "d": R.Discriminator(cfg)}
 
 
-def make_module_fixtures(R):
-    """F2: every reference module, forward + backward, C1 dims, full and ragged lengths."""
-    cfg = c1_cfg()
-    B, T, F, H = 6, 24, 5, 24
-    nets = build_nets(R, cfg, 7)
-    rng = np.random.default_rng(77)
+def make_module_fixtures(R, F=5, name="modules_c1", seed=7):
+    """F2: every reference module, forward + backward, full and ragged lengths; C1 dims (5 features, the
+    sine config) or C2 dims (6 features, the stock config)."""
+    cfg = c1_cfg(F=F)
+    B, T, H = 6, 24, 24
+    nets = build_nets(R, cfg, seed)
+    rng = np.random.default_rng(11 * seed)
     out = {}
     for k, m in nets.items():
         out.update(sd_arrays("sd." + k, m))
@@ -171,17 +173,18 @@ def make_module_fixtures(R):
             out[f"{tag}.{k}.gout"] = gy.numpy().copy()
             out[f"{tag}.{k}.gin"] = xin.grad.numpy().copy()
             out.update(grad_arrays(f"{tag}.{k}.grad", m))
-    path = os.path.join(HERE, "modules_c1.npz")
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"modules_c1: {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def make_loss_fixtures(R):
-    """F3: the five loss builders (TimeGANv1.py:410-553) and the parameter grads they produce."""
-    cfg = c1_cfg()
-    B, T, F = 16, 24, 5
-    nets = build_nets(R, cfg, 11)
-    rng = np.random.default_rng(111)
+def make_loss_fixtures(R, F=5, name="losses_c1", seed=11):
+    """F3: the five loss builders (TimeGANv1.py:410-553) and the parameter grads they produce; C1 dims
+    (5 features) or C2 dims (6 features)."""
+    cfg = c1_cfg(F=F)
+    B, T = 16, 24
+    nets = build_nets(R, cfg, seed)
+    rng = np.random.default_rng(111 if seed == 11 else 101 * seed)
     x = torch.tensor(rng.uniform(0, 1, (B, T, F)), dtype=torch.float32)
     z = torch.tensor(rng.uniform(0, 1, (B, T, F)), dtype=torch.float32)
     t = [T] * B
@@ -238,9 +241,9 @@ def make_loss_fixtures(R):
     with torch.no_grad():
         out["inference.x_hat"] = R._inference(sup=nets["sup"], g=nets["g"], rec=nets["rec"],
                                               z=z, t=t).numpy().copy()
-    path = os.path.join(HERE, "losses_c1.npz")
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"losses_c1: {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def make_step_fixtures(R):
@@ -399,7 +402,7 @@ def make_data_fixtures(ref):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="all", choices=["all", "gru", "ref", "data"])
+    ap.add_argument("--only", default="all", choices=["all", "gru", "ref", "ref_c2", "data"])
     args = ap.parse_args()
     torch.set_num_threads(1)
     if args.only in ("all", "gru"):
@@ -409,5 +412,9 @@ if __name__ == "__main__":
         make_module_fixtures(R)
         make_loss_fixtures(R)
         make_step_fixtures(R)
+    if args.only in ("all", "ref_c2"):      # the stock config's width: 6 features
+        R = import_reference(args.ref)
+        make_module_fixtures(R, F=6, name="modules_c2", seed=13)
+        make_loss_fixtures(R, F=6, name="losses_c2", seed=17)
     if args.only in ("all", "data"):
         make_data_fixtures(args.ref)

@@ -124,3 +124,25 @@ def test_argument_checks_of_the_struct_entry_points():
     assert lb.tgru_loss_layout(0, 24, 6, lay) == 0 and int(lay[1]) == 0
     assert lb.tgru_loss_layout(7, 24, 6, lay) == E_DIMS
     assert lb.tgru_loss_final(0, 4, 3, 5, 6, 1.0, None, None) == E_NULL
+
+
+def test_no_gfx950_device_is_reported_not_launched():
+    """With valid-looking arguments but no gfx950 GPU as the current device, tgru_forward / tgru_backward
+    return TGRU_E_NOGPU before anything is launched (the pointers below are never dereferenced)."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the device check passes here")
+    import timegan_amd as tg
+    lb = tg.lib()
+    E_NOGPU = -6
+    B, T, In, H, L = 4, 3, 8, 8, 1
+    fake = ctypes.c_void_p(0x1000)            # 16-byte aligned, non-NULL
+    arr = (ctypes.c_void_p * L)(0x1000)
+    rc = lb.tgru_forward(fake, None, None, None, arr, arr, arr, arr, fake, None, fake, fake,
+                         B, T, In, H, L, tg.LAYOUT_TBF, None)
+    assert rc == E_NOGPU
+    assert b"gfx950" in lb.tgru_error_string(rc)
+    rc = lb.tgru_backward(fake, None, fake, None, fake, None, None, arr, arr, arr, arr, fake, fake, fake, None,
+                          arr, arr, arr, arr, B, T, In, H, L, tg.LAYOUT_TBF, 0, None)
+    assert rc == E_NOGPU
+    n0 = tg.launch_count()
+    assert tg.launch_count() == n0            # nothing was launched by the rejected calls

@@ -14,11 +14,12 @@ def _nets():
     return {k: m.to("cuda:0") for k, m in tg.build_networks(cfg).items()}
 
 
-def _grads(nets, deferred, twice, freeze):
+def _grads(nets, deferred, twice, freeze, zero=True):
     from timegan_amd.deferred import deferred_reductions
     from timegan_amd.modules import forward_pair
     for m in nets.values():
-        m.zero_grad()
+        if zero:
+            m.zero_grad()
         for p in m.parameters():
             p.requires_grad_(True)
     if freeze:
@@ -54,3 +55,27 @@ def test_deferred_equals_immediate(twice, freeze):
             assert got[k] is None, k
         else:
             assert torch.equal(got[k], ref[k]), f"{k}: max diff {float((got[k] - ref[k]).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("set_to_none", [True, False])
+def test_deferred_passes_accumulate_into_existing_gradients(set_to_none):
+    """Two backward passes without zeroing in between (gradient accumulation), and a pass over gradients
+    zeroed in place (zero_grad(set_to_none=False)): autograd ADDS an arriving gradient to an existing one at
+    once, so such a gradient must not be deferred."""
+    nets = _nets()
+    once = _grads(nets, False, False, False)
+    if set_to_none:
+        _grads(nets, True, False, False)                       # first pass fills .grad
+        got = _grads(nets, True, False, False, zero=False)     # second pass adds to it
+        want = {k: None if v is None else 2 * v for k, v in once.items()}
+    else:
+        for m in nets.values():
+            m.zero_grad(set_to_none=False)                     # .grad stays a tensor of zeros
+        got = _grads(nets, True, False, False, zero=False)
+        want = once
+    for k in want:
+        if want[k] is None:
+            assert got[k] is None, k
+        else:
+            assert torch.allclose(got[k], want[k], rtol=1e-6, atol=0), \
+                f"{k}: max diff {float((got[k] - want[k]).abs().max()):.3e}"

@@ -107,6 +107,8 @@ def kernel_path(request, monkeypatch):
     elif request.param == "small":
         monkeypatch.setenv("TGRU_NO_VEC", "1")
         monkeypatch.setenv("TGRU_NO_H24", "1")
+    import timegan_amd as tg
+    tg.reload_switches()
     return request.param
 
 

@@ -144,6 +144,7 @@ def test_large_hidden_with_initial_state_and_ragged_lengths(per_step, monkeypatc
         monkeypatch.delenv("TGRU_NO_STEP", raising=False)
     else:
         monkeypatch.setenv("TGRU_NO_STEP", "1")
+    tg.reload_switches()
     for (B, T, In, H, L, lens) in ((300, 5, 40, 160, 2, [5] * 100 + [4] * 50 + [2] * 100 + [1] * 50),
                                    (130, 3, 256, 256, 1, None),
                                    (5, 7, 20, 192, 3, [7, 7, 3, 2, 1])):

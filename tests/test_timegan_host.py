@@ -15,9 +15,9 @@ from helpers import GOLDEN, assert_close
 NETS = ("emb", "rec", "sup", "g", "d")
 
 
-def _cfg(threshold=0.15):
+def _cfg(threshold=0.15, features=5):
     import timegan_amd as tg
-    return tg.make_cfg(features=5, hidden=24, layers=3, seq_len=24, threshold=threshold, device="cpu")
+    return tg.make_cfg(features=features, hidden=24, layers=3, seq_len=24, threshold=threshold, device="cpu")
 
 
 def _load_sd(d, prefix, nets, device):
@@ -27,10 +27,10 @@ def _load_sd(d, prefix, nets, device):
         nets[k].load_state_dict(sd)
 
 
-def _build(device, on_gpu):
+def _build(device, on_gpu, features=5):
     import timegan_amd as tg
     kw = {} if on_gpu else {"rnn_cls": torch.nn.GRU}
-    nets = tg.build_networks(_cfg(), **kw)
+    nets = tg.build_networks(_cfg(features=features), **kw)
     return {k: m.to(device) for k, m in nets.items()}
 
 
@@ -44,9 +44,13 @@ def _check_grads(d, tag, nets, rtol, atol_scale):
             assert_close(got, d[key], rtol, atol_scale, key)
 
 
-def _modules(device, on_gpu):
-    d = np.load(os.path.join(GOLDEN, "modules_c1.npz"))
-    nets = _build(device, on_gpu)
+# fixtures at the sine config's 5 features (c1) and the stock config's 6 features (c2)
+FEATURES = {"c1": 5, "c2": 6}
+
+
+def _modules(device, on_gpu, dims="c1"):
+    d = np.load(os.path.join(GOLDEN, f"modules_{dims}.npz"))
+    nets = _build(device, on_gpu, FEATURES[dims])
     _load_sd(d, "sd.", nets, device)
     for tag in ("full", "ragged"):
         t = [int(v) for v in d[f"{tag}.t"]]
@@ -62,11 +66,11 @@ def _modules(device, on_gpu):
                              f"{tag}.{k}.grad.{name}")
 
 
-def _losses(device, on_gpu):
+def _losses(device, on_gpu, dims="c1"):
     import timegan_amd as tg
     L = tg.losses
-    d = np.load(os.path.join(GOLDEN, "losses_c1.npz"))
-    nets = _build(device, on_gpu)
+    d = np.load(os.path.join(GOLDEN, f"losses_{dims}.npz"))
+    nets = _build(device, on_gpu, FEATURES[dims])
     _load_sd(d, "sd.", nets, device)
     x = torch.from_numpy(d["x"]).to(device)
     z = torch.from_numpy(d["z"]).to(device)
@@ -156,12 +160,14 @@ def _steps(device, on_gpu, use_graphs=False):
         check_params(f"after_{tag}", 5e-3, 5e-4)
 
 
-def test_modules_match_reference_cpu():
-    _modules(torch.device("cpu"), False)
+@pytest.mark.parametrize("dims", ["c1", "c2"])
+def test_modules_match_reference_cpu(dims):
+    _modules(torch.device("cpu"), False, dims)
 
 
-def test_losses_match_reference_cpu():
-    _losses(torch.device("cpu"), False)
+@pytest.mark.parametrize("dims", ["c1", "c2"])
+def test_losses_match_reference_cpu(dims):
+    _losses(torch.device("cpu"), False, dims)
 
 
 def test_training_steps_match_reference_cpu():
@@ -169,13 +175,15 @@ def test_training_steps_match_reference_cpu():
 
 
 @pytest.mark.gpu
-def test_modules_match_reference_gpu():
-    _modules(torch.device("cuda:0"), True)
+@pytest.mark.parametrize("dims", ["c1", "c2"])
+def test_modules_match_reference_gpu(dims):
+    _modules(torch.device("cuda:0"), True, dims)
 
 
 @pytest.mark.gpu
-def test_losses_match_reference_gpu():
-    _losses(torch.device("cuda:0"), True)
+@pytest.mark.parametrize("dims", ["c1", "c2"])
+def test_losses_match_reference_gpu(dims):
+    _losses(torch.device("cuda:0"), True, dims)
 
 
 @pytest.mark.gpu

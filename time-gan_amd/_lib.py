@@ -62,6 +62,8 @@ MAX_JOBS_PER_CALL = 32    # upper bound of jobs one backward call can owe (5 per
 # name -> (restype, argtypes); mirrors include/tgru.h one to one
 SIGNATURES = {
     "tgru_version": (_i, []),
+    "tgru_launch_count": (ctypes.c_ulonglong, []),
+    "tgru_reload_switches": (None, []),
     "tgru_error_string": (ctypes.c_char_p, [_i]),
     "tgru_reserve_bytes": (ctypes.c_size_t, [_i] * 6),
     "tgru_forward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
@@ -133,6 +135,16 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def reload_switches():
+    """Make the library read its TGRU_* environment switches again (it reads them once per process)."""
+    lib().tgru_reload_switches()
+
+
+def launch_count() -> int:
+    """Kernel launches the library has issued in this process so far."""
+    return int(lib().tgru_launch_count())
 
 
 def check(code: int, what: str):

@@ -73,6 +73,6 @@ extern "C" int tgru_adam_jobs(const tgru_adam_job *jobs, int n_jobs, float lr, f
     t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps;
     t.log_beta1 = (float)log((double)beta1); t.log_beta2 = (float)log((double)beta2);
     t.skip = skip;
-    hipLaunchKernelGGL(adam::adam_jobs_kernel, dim3(n_jobs), dim3(adam::kThreads), 0, (hipStream_t)stream, t);
+    TGRU_LAUNCH(adam::adam_jobs_kernel, dim3(n_jobs), dim3(adam::kThreads), 0, (hipStream_t)stream, t);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }

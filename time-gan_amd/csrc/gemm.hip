@@ -295,7 +295,7 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // may every operand load of this product be an unconditional 16-byte load?
 static bool fast_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
-    if (getenv("TGRU_GEMM_GUARDED")) return false;   // tests: keep the guarded loads covered
+    if (switches().gemm_guarded) return false;   // tests: keep the guarded loads covered
     if (!aligned16(g.A) || !aligned16(g.Bm) || (g.lda & 3) || (g.ldb & 3)) return false;
     if (g.K < BK || (g.K % BK) || (nslabs > 1 && (g.kchunk % BK))) return false;
     if (nslabs == 1 && g.kchunk < g.K) return false;
@@ -314,13 +314,13 @@ static hipError_t launch_cfg(const GemmArgs &g0, bool a_kc, bool b_kc, int nslab
     dim3 grid((unsigned)(8 * ((ngroups + 7) / 8) * gsize));
     dim3 block(NTHREADS);
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, g);
+        TGRU_LAUNCH((gemm_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, g);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, g);
+        TGRU_LAUNCH((gemm_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, g);
     else if (!a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, g);
+        TGRU_LAUNCH((gemm_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, g);
+        TGRU_LAUNCH((gemm_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, g);
     return hipGetLastError();
 }
 
@@ -360,7 +360,7 @@ hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float
                               int accumulate, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, stride, nslabs, out,
+    TGRU_LAUNCH(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, stride, nslabs, out,
                        n, accumulate);
     return hipGetLastError();
 }

@@ -413,11 +413,11 @@ hipError_t launch_gru_h24_fwd(const SmallFwdArgs &a, hipStream_t s) {
     // FAST needs closed-form row addressing (no packed rows) and 32-bit byte offsets
     const bool fast = vec && !big && a.xmap.mode != 2 && a.ymap.mode != 2 &&
                       (long)a.T * a.B * a.H * 16 < (1L << 30) && (long)a.T * a.B * a.In * 4 < (1L << 30);
-    if (fast) hipLaunchKernelGGL((gru_h24_fwd_kernel<512, true, true>), grid, block, lds, s, a);
-    else if (!big && vec) hipLaunchKernelGGL((gru_h24_fwd_kernel<512, true, false>), grid, block, lds, s, a);
-    else if (!big) hipLaunchKernelGGL((gru_h24_fwd_kernel<512, false, false>), grid, block, lds, s, a);
-    else if (vec) hipLaunchKernelGGL((gru_h24_fwd_kernel<1024, true, false>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_h24_fwd_kernel<1024, false, false>), grid, block, lds, s, a);
+    if (fast) TGRU_LAUNCH((gru_h24_fwd_kernel<512, true, true>), grid, block, lds, s, a);
+    else if (!big && vec) TGRU_LAUNCH((gru_h24_fwd_kernel<512, true, false>), grid, block, lds, s, a);
+    else if (!big) TGRU_LAUNCH((gru_h24_fwd_kernel<512, false, false>), grid, block, lds, s, a);
+    else if (vec) TGRU_LAUNCH((gru_h24_fwd_kernel<1024, true, false>), grid, block, lds, s, a);
+    else TGRU_LAUNCH((gru_h24_fwd_kernel<1024, false, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
@@ -701,11 +701,11 @@ hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s) {
     const bool big = block.x > 512, vec = (a.In & 3) == 0 && (a.H & 3) == 0;
     const bool fast = vec && !big && a.dymap.mode != 2 && a.dxmap.mode != 2 &&
                       (long)a.T * a.B * a.H * 16 < (1L << 30) && (long)a.T * a.B * a.In * 4 < (1L << 30);
-    if (fast) hipLaunchKernelGGL((gru_h24_bwd_kernel<512, true, true>), grid, block, lds, s, a);
-    else if (!big && vec) hipLaunchKernelGGL((gru_h24_bwd_kernel<512, true, false>), grid, block, lds, s, a);
-    else if (!big) hipLaunchKernelGGL((gru_h24_bwd_kernel<512, false, false>), grid, block, lds, s, a);
-    else if (vec) hipLaunchKernelGGL((gru_h24_bwd_kernel<1024, true, false>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_h24_bwd_kernel<1024, false, false>), grid, block, lds, s, a);
+    if (fast) TGRU_LAUNCH((gru_h24_bwd_kernel<512, true, true>), grid, block, lds, s, a);
+    else if (!big && vec) TGRU_LAUNCH((gru_h24_bwd_kernel<512, true, false>), grid, block, lds, s, a);
+    else if (!big) TGRU_LAUNCH((gru_h24_bwd_kernel<512, false, false>), grid, block, lds, s, a);
+    else if (vec) TGRU_LAUNCH((gru_h24_bwd_kernel<1024, true, false>), grid, block, lds, s, a);
+    else TGRU_LAUNCH((gru_h24_bwd_kernel<1024, false, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 

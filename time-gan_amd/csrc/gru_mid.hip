@@ -377,9 +377,9 @@ hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s) {
     const int HP = a.H <= 64 ? 64 : (a.H <= 96 ? 96 : 128);
     const int NI = (4 * HP + 63) / 64 + 2 * ((HP + 63) / 64);
     const size_t lds = (size_t)(mid::kSlots * NI * 256 + mid::kSeq * 3 * HP + 3 * mid::kSeq * nhs * 64) * sizeof(float);
-    if (HP == 64) hipLaunchKernelGGL(gru_mid_bwd_kernel<64>, grid, block, lds, s, a);
-    else if (HP == 96) hipLaunchKernelGGL(gru_mid_bwd_kernel<96>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gru_mid_bwd_kernel<128>, grid, block, lds, s, a);
+    if (HP == 64) TGRU_LAUNCH(gru_mid_bwd_kernel<64>, grid, block, lds, s, a);
+    else if (HP == 96) TGRU_LAUNCH(gru_mid_bwd_kernel<96>, grid, block, lds, s, a);
+    else TGRU_LAUNCH(gru_mid_bwd_kernel<128>, grid, block, lds, s, a);
     return hipGetLastError();
 }
 
@@ -389,9 +389,9 @@ hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s) {
     const int HP = a.H <= 64 ? 64 : (a.H <= 96 ? 96 : 128);
     const int NI = (3 * HP + 63) / 64;
     const size_t lds = (size_t)(2 * mid::kSeq * HP + mid::kSeq * nw * 64 + mid::kSlots * NI * 256) * sizeof(float);
-    if (HP == 64) hipLaunchKernelGGL(gru_mid_fwd_kernel<64>, grid, block, lds, s, a);
-    else if (HP == 96) hipLaunchKernelGGL(gru_mid_fwd_kernel<96>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gru_mid_fwd_kernel<128>, grid, block, lds, s, a);
+    if (HP == 64) TGRU_LAUNCH(gru_mid_fwd_kernel<64>, grid, block, lds, s, a);
+    else if (HP == 96) TGRU_LAUNCH(gru_mid_fwd_kernel<96>, grid, block, lds, s, a);
+    else TGRU_LAUNCH(gru_mid_fwd_kernel<128>, grid, block, lds, s, a);
     return hipGetLastError();
 }
 

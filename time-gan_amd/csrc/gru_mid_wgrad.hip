@@ -214,11 +214,11 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
         if (e != hipSuccess) return e;
     }
     const int used = (K + a.rows_per_wg - 1) / a.rows_per_wg;     // workgroups that own rows
-    hipLaunchKernelGGL(gru_mid_wgrad_kernel, dim3(used), dim3(64 * nwaves), lds, s, a);
+    TGRU_LAUNCH(gru_mid_wgrad_kernel, dim3(used), dim3(64 * nwaves), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long na = 3L * H * In, nb = 3L * H * H;
-    hipLaunchKernelGGL(mid_wgrad_reduce_kernel, dim3((unsigned)((na + nb + 31) / 32)), dim3(256), 0, s, slabs,
+    TGRU_LAUNCH(mid_wgrad_reduce_kernel, dim3((unsigned)((na + nb + 31) / 32)), dim3(256), 0, s, slabs,
                        a.slab_stride, used, dw_ih, na, dw_hh, nb, accumulate);
     return hipGetLastError();
 }

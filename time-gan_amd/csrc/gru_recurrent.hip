@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float *__restrict__
 hipError_t launch_pack_whh(const float *w_hh, float *wp, float *wtp, int H, hipStream_t s) {
     const long total = (long)packed_whh_floats(H);
     const int blocks = (int)min((total + 255) / 256, (long)2048);
-    hipLaunchKernelGGL(pack_whh_kernel, dim3(blocks), dim3(256), 0, s, w_hh, wp, wtp, H);
+    TGRU_LAUNCH(pack_whh_kernel, dim3(blocks), dim3(256), 0, s, w_hh, wp, wtp, H);
     return hipGetLastError();
 }
 
@@ -293,11 +293,11 @@ static hipError_t set_lds(K kernel, size_t bytes) {
         hipError_t e_ = hipSuccess;                                                                 \
         dim3 block_((cfg).nw * 64);                                                                 \
         switch ((cfg).tpw * 2 + ((cfg).wlds ? 1 : 0)) {                                             \
-        case 3: e_ = set_lds(KERNEL<1, true>, (cfg).lds); if (e_ == hipSuccess) hipLaunchKernelGGL((KERNEL<1, true>), grid, block_, (cfg).lds, s, args); break;   \
-        case 2: e_ = set_lds(KERNEL<1, false>, (cfg).lds); if (e_ == hipSuccess) hipLaunchKernelGGL((KERNEL<1, false>), grid, block_, (cfg).lds, s, args); break; \
-        case 5: e_ = set_lds(KERNEL<2, true>, (cfg).lds); if (e_ == hipSuccess) hipLaunchKernelGGL((KERNEL<2, true>), grid, block_, (cfg).lds, s, args); break;   \
-        case 4: e_ = set_lds(KERNEL<2, false>, (cfg).lds); if (e_ == hipSuccess) hipLaunchKernelGGL((KERNEL<2, false>), grid, block_, (cfg).lds, s, args); break; \
-        case 8: e_ = set_lds(KERNEL<4, false>, (cfg).lds); if (e_ == hipSuccess) hipLaunchKernelGGL((KERNEL<4, false>), grid, block_, (cfg).lds, s, args); break; \
+        case 3: e_ = set_lds(KERNEL<1, true>, (cfg).lds); if (e_ == hipSuccess) TGRU_LAUNCH((KERNEL<1, true>), grid, block_, (cfg).lds, s, args); break;   \
+        case 2: e_ = set_lds(KERNEL<1, false>, (cfg).lds); if (e_ == hipSuccess) TGRU_LAUNCH((KERNEL<1, false>), grid, block_, (cfg).lds, s, args); break; \
+        case 5: e_ = set_lds(KERNEL<2, true>, (cfg).lds); if (e_ == hipSuccess) TGRU_LAUNCH((KERNEL<2, true>), grid, block_, (cfg).lds, s, args); break;   \
+        case 4: e_ = set_lds(KERNEL<2, false>, (cfg).lds); if (e_ == hipSuccess) TGRU_LAUNCH((KERNEL<2, false>), grid, block_, (cfg).lds, s, args); break; \
+        case 8: e_ = set_lds(KERNEL<4, false>, (cfg).lds); if (e_ == hipSuccess) TGRU_LAUNCH((KERNEL<4, false>), grid, block_, (cfg).lds, s, args); break; \
         default: e_ = hipErrorInvalidValue;                                                         \
         }                                                                                           \
         if (e_ != hipSuccess) return e_;                                                            \
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(32 * kBiasGroups) void bias_grad_kernel(const float
 
 hipError_t launch_bias_grad(const float *db_part, int nblocks, int H, float *db_ih, float *db_hh,
                             int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((4 * H + 31) / 32), dim3(32 * kBiasGroups), 0, s, db_part, nblocks, H,
+    TGRU_LAUNCH(bias_grad_kernel, dim3((4 * H + 31) / 32), dim3(32 * kBiasGroups), 0, s, db_part, nblocks, H,
                        db_ih, db_hh, accumulate);
     return hipGetLastError();
 }

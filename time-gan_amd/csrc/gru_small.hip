@@ -290,16 +290,16 @@ extern "C" int tgru_debug_stamps(unsigned long long *out) {
 
 template <int NT, int MAXT>
 static hipError_t launch_fwd_t(const SmallFwdArgs &a, dim3 grid, dim3 block, size_t lds, bool vec, hipStream_t s) {
-    if (vec) hipLaunchKernelGGL((gru_small_fwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_small_fwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
+    if (vec) TGRU_LAUNCH((gru_small_fwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
+    else TGRU_LAUNCH((gru_small_fwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
 static bool all_vec(int In, int H) { return (In & 3) == 0 && (H & 3) == 0; }
 
 static bool h24_shape(int In, int H) {
-    const char *e = getenv("TGRU_NO_H24");   // tests use this to reach the generic small-H kernels at H = 24
-    return H > 16 && H <= 24 && In <= 24 && !(e && e[0] == '1');
+    // TGRU_NO_H24=1: the tests use it to reach the generic small-H kernels at H = 24
+    return H > 16 && H <= 24 && In <= 24 && !switches().no_h24;
 }
 
 hipError_t launch_gru_small_fwd(const SmallFwdArgs &a, hipStream_t s) {
@@ -534,8 +534,8 @@ static hipError_t launch_bwd_t(const SmallBwdArgs &a, dim3 grid, dim3 block, siz
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (vec) hipLaunchKernelGGL((gru_small_bwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gru_small_bwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
+    if (vec) TGRU_LAUNCH((gru_small_bwd_kernel<NT, MAXT, true>), grid, block, lds, s, a);
+    else TGRU_LAUNCH((gru_small_bwd_kernel<NT, MAXT, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 

@@ -391,7 +391,7 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, hipStream_t s) {
     for (int t = 0; t < a.T; ++t) {
         k.t = t;
         k.hprev = t ? ysrc + (size_t)(t - 1) * a.B * a.H : a.h0;
-        hipLaunchKernelGGL(gru_step_fwd_kernel, grid, dim3(256), 0, s, k);
+        TGRU_LAUNCH(gru_step_fwd_kernel, grid, dim3(256), 0, s, k);
     }
     return hipGetLastError();
 }
@@ -407,7 +407,7 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
     for (int t = a.T - 1; t >= (a.dh0 ? -1 : 0); --t) {
         k.t = t;
         k.first = t == a.T - 1;
-        hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, s, k);
+        TGRU_LAUNCH(gru_step_bwd_kernel, grid, dim3(256), 0, s, k);
     }
     return hipGetLastError();
 }

@@ -568,10 +568,10 @@ hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, const SmallFwdArgs *second,
     }
     dim3 grid(ga.nwg0 + ga.nwg1), block(64 * (a.L + 1));
     const size_t lds = (size_t)(2 * a.L * KP + vec::kFwdSlots * 32) * sizeof(float);
-    if (k24 && second) hipLaunchKernelGGL((gru_vec_fwd_kernel<24, true>), grid, block, lds, s, ga);
-    else if (k24) hipLaunchKernelGGL((gru_vec_fwd_kernel<24, false>), grid, block, lds, s, ga);
-    else if (second) hipLaunchKernelGGL((gru_vec_fwd_kernel<32, true>), grid, block, lds, s, ga);
-    else hipLaunchKernelGGL((gru_vec_fwd_kernel<32, false>), grid, block, lds, s, ga);
+    if (k24 && second) TGRU_LAUNCH((gru_vec_fwd_kernel<24, true>), grid, block, lds, s, ga);
+    else if (k24) TGRU_LAUNCH((gru_vec_fwd_kernel<24, false>), grid, block, lds, s, ga);
+    else if (second) TGRU_LAUNCH((gru_vec_fwd_kernel<32, true>), grid, block, lds, s, ga);
+    else TGRU_LAUNCH((gru_vec_fwd_kernel<32, false>), grid, block, lds, s, ga);
     return hipGetLastError();
 }
 
@@ -587,10 +587,10 @@ hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, const SmallBwdArgs *second,
     }
     dim3 grid(ga.nwg0 + ga.nwg1), block(64 * (a.L + 1));
     const size_t lds = (size_t)((4 * a.L + 2 * a.L) * KP + vec::kBwdSlots * vec::kSlotFloats) * sizeof(float);
-    if (k24 && second) hipLaunchKernelGGL((gru_vec_bwd_kernel<24, true>), grid, block, lds, s, ga);
-    else if (k24) hipLaunchKernelGGL((gru_vec_bwd_kernel<24, false>), grid, block, lds, s, ga);
-    else if (second) hipLaunchKernelGGL((gru_vec_bwd_kernel<32, true>), grid, block, lds, s, ga);
-    else hipLaunchKernelGGL((gru_vec_bwd_kernel<32, false>), grid, block, lds, s, ga);
+    if (k24 && second) TGRU_LAUNCH((gru_vec_bwd_kernel<24, true>), grid, block, lds, s, ga);
+    else if (k24) TGRU_LAUNCH((gru_vec_bwd_kernel<24, false>), grid, block, lds, s, ga);
+    else if (second) TGRU_LAUNCH((gru_vec_bwd_kernel<32, true>), grid, block, lds, s, ga);
+    else TGRU_LAUNCH((gru_vec_bwd_kernel<32, false>), grid, block, lds, s, ga);
     return hipGetLastError();
 }
 

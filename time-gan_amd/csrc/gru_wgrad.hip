@@ -205,7 +205,7 @@ int small_wgrad_chunks(int B, int T) {
 
 hipError_t launch_gru_small_wgrad(const SmallWgradArgs &a, hipStream_t s) {
     const size_t lds = (size_t)(kWgRows * wg_ldg(a.H) + 2 * kWgRows * kWgLdx) * sizeof(float);
-    hipLaunchKernelGGL(gru_wgrad_partial_kernel, dim3(a.nchunks, a.L), dim3(512), lds, s, a);
+    TGRU_LAUNCH(gru_wgrad_partial_kernel, dim3(a.nchunks, a.L), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_gru_small_wgrad_reduce(a, nullptr, s);
@@ -224,7 +224,7 @@ hipError_t launch_gru_small_wgrad_reduce(const SmallWgradArgs &a, const SmallWgr
         ga.g[1] = *second;
         ga.nwg1 = reduce_workgroups(*second);
     }
-    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((unsigned)(ga.nwg0 + ga.nwg1)), dim3(kRedElems * kRedGroups), 0,
+    TGRU_LAUNCH(gru_wgrad_reduce_kernel, dim3((unsigned)(ga.nwg0 + ga.nwg1)), dim3(kRedElems * kRedGroups), 0,
                        s, ga);
     return hipGetLastError();
 }

@@ -573,10 +573,10 @@ hipError_t head_launch(const head::Args &a, const head::Args *second, hipStream_
     const bool wide = dmid > 32;
 #define TGRU_HEAD_LAUNCH(K)                                                                       \
     do {                                                                                          \
-        if (wide && second) hipLaunchKernelGGL((head::K<4, true>), grid, block, 0, s, ga);        \
-        else if (wide) hipLaunchKernelGGL((head::K<4, false>), grid, block, 0, s, ga);            \
-        else if (second) hipLaunchKernelGGL((head::K<2, true>), grid, block, 0, s, ga);           \
-        else hipLaunchKernelGGL((head::K<2, false>), grid, block, 0, s, ga);                      \
+        if (wide && second) TGRU_LAUNCH((head::K<4, true>), grid, block, 0, s, ga);        \
+        else if (wide) TGRU_LAUNCH((head::K<4, false>), grid, block, 0, s, ga);            \
+        else if (second) TGRU_LAUNCH((head::K<2, true>), grid, block, 0, s, ga);           \
+        else TGRU_LAUNCH((head::K<2, false>), grid, block, 0, s, ga);                      \
     } while (0)
     if (BWD) TGRU_HEAD_LAUNCH(head_bwd_kernel);
     else TGRU_HEAD_LAUNCH(head_fwd_kernel);
@@ -596,7 +596,7 @@ hipError_t head_reduce_launch(const tgru_head_args &a, const tgru_head_args *sec
         nwg[k] = (total + 31) / 32;
     }
     ga.nwg0 = nwg[0]; ga.nwg1 = nwg[1];
-    hipLaunchKernelGGL(head::head_reduce_kernel, dim3(nwg[0] + nwg[1]), dim3(32 * head::kRedGroups), 0, s, ga);
+    TGRU_LAUNCH(head::head_reduce_kernel, dim3(nwg[0] + nwg[1]), dim3(32 * head::kRedGroups), 0, s, ga);
     return hipGetLastError();
 }
 

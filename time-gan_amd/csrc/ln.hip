@@ -156,7 +156,7 @@ int tgru_layer_norm_forward(const float *x, const float *gamma, const float *bet
     if (!x || !y || !stats) return TGRU_E_NULL;
     if (!ln::aligned16(x) || !ln::aligned16(y) || (gamma && !ln::aligned16(gamma)) || (beta && !ln::aligned16(beta)))
         return TGRU_E_ALIGN;
-    hipLaunchKernelGGL(ln::ln_fwd_kernel, dim3(ln::workgroups(rows)), dim3(ln::kThreads), 0, (hipStream_t)stream, x, gamma,
+    TGRU_LAUNCH(ln::ln_fwd_kernel, dim3(ln::workgroups(rows)), dim3(ln::kThreads), 0, (hipStream_t)stream, x, gamma,
                        beta, y, stats, rows, width, eps);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
@@ -169,10 +169,10 @@ int tgru_layer_norm_backward(const float *x, const float *dy, const float *stats
     if (!ln::aligned16(x) || !ln::aligned16(dy) || (dx && !ln::aligned16(dx)) || (gamma && !ln::aligned16(gamma)))
         return TGRU_E_ALIGN;
     const int nwg = ln::workgroups(rows);
-    hipLaunchKernelGGL(ln::ln_bwd_kernel, dim3(nwg), dim3(ln::kThreads), 0, (hipStream_t)stream, x, dy, stats, gamma, dx,
+    TGRU_LAUNCH(ln::ln_bwd_kernel, dim3(nwg), dim3(ln::kThreads), 0, (hipStream_t)stream, x, dy, stats, gamma, dx,
                        workspace, rows, width);
     if (dgamma || dbeta)
-        hipLaunchKernelGGL(ln::ln_bwd_reduce_kernel, dim3((2 * width + 31) / 32),
+        TGRU_LAUNCH(ln::ln_bwd_reduce_kernel, dim3((2 * width + 31) / 32),
                            dim3(ln::kThreads), 0, (hipStream_t)stream, workspace, nwg, width, dgamma, dbeta, accumulate);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }

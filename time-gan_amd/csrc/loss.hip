@@ -369,7 +369,7 @@ int tgru_loss_partial(int kind, int pass, const float *const *in, int B, int T, 
     a.pass = pass; a.buf = buf;
     const int nmb = (a.C + loss::kCols - 1) / loss::kCols;
     const int grid = (pass == 2 ? 0 : 3 * loss::kSlots) + nmb;
-    hipLaunchKernelGGL(loss::loss_partial_kernel, dim3(grid), dim3(loss::kThreads), 0, (hipStream_t)stream, a);
+    TGRU_LAUNCH(loss::loss_partial_kernel, dim3(grid), dim3(loss::kThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
 
@@ -382,7 +382,7 @@ int tgru_loss_final(int kind, int B, int T, int H, int F, float gamma, float *bu
     const int rc = loss::fill_args(a, kind, none, nullptr, B, T, H, F);
     if (rc != TGRU_OK) return rc;
     a.gamma = gamma; a.buf = buf;
-    hipLaunchKernelGGL(loss::loss_final_kernel, dim3(1), dim3(loss::kThreads), 0, (hipStream_t)stream, a);
+    TGRU_LAUNCH(loss::loss_final_kernel, dim3(1), dim3(loss::kThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
 
@@ -397,7 +397,7 @@ int tgru_loss_backward(int kind, const float *const *in, float *const *din, cons
     const long nm = (long)B * a.C;
     long nmb = (nm + loss::kThreads - 1) / loss::kThreads;
     if (nmb > 1024) nmb = 1024;
-    hipLaunchKernelGGL(loss::loss_backward_kernel, dim3(3 * loss::kSlots + (int)nmb), dim3(loss::kThreads), 0,
+    TGRU_LAUNCH(loss::loss_backward_kernel, dim3(3 * loss::kSlots + (int)nmb), dim3(loss::kThreads), 0,
                        (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }

@@ -87,7 +87,7 @@ extern "C" int tgru_reduce_jobs(const tgru_reduce_job *jobs, int n_jobs, tgru_st
         }
         t.first[n] = blocks;
         t.n = n;
-        hipLaunchKernelGGL(red::reduce_jobs_kernel, dim3(blocks), dim3(red::kElems * red::kGroups), 0,
+        TGRU_LAUNCH(red::reduce_jobs_kernel, dim3(blocks), dim3(red::kElems * red::kGroups), 0,
                            (hipStream_t)stream, t);
         if (hipGetLastError() != hipSuccess) return TGRU_E_LAUNCH;
     }

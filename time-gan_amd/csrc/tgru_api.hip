@@ -2,8 +2,30 @@
 #include "../../include/tgru.h"
 #include "tgru_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 using namespace tgru;
+
+namespace tgru {
+std::atomic<unsigned long long> g_launches{0};
+
+void Switches::read() {
+    auto on = [](const char *name) {
+        const char *e = getenv(name);
+        return e && e[0] == '1';
+    };
+    force_generic = on("TGRU_FORCE_GENERIC");
+    no_vec = on("TGRU_NO_VEC");
+    no_mid = on("TGRU_NO_MID");
+    no_step = on("TGRU_NO_STEP");
+    no_h24 = on("TGRU_NO_H24");
+    gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
+}
+Switches &switches() {
+    static Switches s;
+    return s;
+}
+}  // namespace tgru
 
 namespace {
 
@@ -28,37 +50,52 @@ int check_dims(int B, int T, int In, int H, int L, int layout) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Small stacks run as whole-stack kernels (gru_small.hip).  TGRU_FORCE_GENERIC=1 in the
-// environment selects the per-layer kernels instead (used by the tests to cover both paths).
+// Kernel-family switches from the environment, read ONCE per process (tgru_reload_switches() reads them
+// again; the tests use it to cover every family on the same fixtures):
+//   TGRU_FORCE_GENERIC=1  per-layer kernels instead of the whole-stack kernels of gru_small.hip
+//   TGRU_NO_VEC=1         MFMA whole-stack kernels instead of one sequence per workgroup (gru_vec.hip)
+//   TGRU_NO_MID=1         16-sequence kernels of gru_recurrent.hip instead of gru_mid.hip (32 < H <= 128)
+//   TGRU_NO_STEP=1        persistent 16-sequence kernels instead of one launch per step (gru_step.hip)
+//   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
+//   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
 bool use_small(int In, int H, int L) {
     if (H > kSmallMaxH || In > kSmallMaxIn || L > kSmallMaxL) return false;
-    const char *e = getenv("TGRU_FORCE_GENERIC");
-    return !(e && e[0] == '1');
+    return !switches().force_generic;
 }
 
 // Small stacks with up to 1024 sequences in a padded layout run one sequence per workgroup on the
-// vector ALU (gru_vec.hip); TGRU_NO_VEC=1 selects the MFMA whole-stack kernels for them instead.
+// vector ALU (gru_vec.hip).
 bool use_vec(int B, int T, int In, int H, int L, int layout) {
     if (layout == TGRU_LAYOUT_PACKED) return false;
     if (!use_small(In, H, L) || !gru_vec_supported(B, T, In, H, L)) return false;
-    const char *e = getenv("TGRU_NO_VEC");
-    return !(e && e[0] == '1');
+    return !switches().no_vec;
 }
 
-// 32 < H <= 128: recurrent kernels with four sequences per workgroup (gru_mid.hip); TGRU_NO_MID=1
-// selects the 16-sequence MFMA kernels of gru_recurrent.hip instead.
-bool use_mid(int H) {
-    if (!gru_mid_supported(H)) return false;
-    const char *e = getenv("TGRU_NO_MID");
-    return !(e && e[0] == '1');
-}
+// 32 < H <= 128: recurrent kernels with four sequences per workgroup (gru_mid.hip).
+bool use_mid(int H) { return gru_mid_supported(H) && !switches().no_mid; }
 
-// H > 128 (multiples of 32): one launch per time step (gru_step.hip); TGRU_NO_STEP=1 selects the
-// persistent 16-sequence kernels of gru_recurrent.hip instead.
-bool use_step(int B, int H) {
-    if (!gru_step_supported(B, H)) return false;
-    const char *e = getenv("TGRU_NO_STEP");
-    return !(e && e[0] == '1');
+// H > 128 (multiples of 32): one launch per time step (gru_step.hip).
+bool use_step(int B, int H) { return gru_step_supported(B, H) && !switches().no_step; }
+
+// The kernels are built for gfx950 only.  The architecture of each device is looked up once
+// (0 = not looked up yet, 1 = gfx950, -1 = anything else, or no device at all).
+int device_ok() {
+    constexpr int kMaxDev = 64;
+    static std::atomic<signed char> known[kMaxDev];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        (void)hipGetLastError();
+        return TGRU_E_NOGPU;
+    }
+    signed char k = known[dev].load(std::memory_order_relaxed);
+    if (k == 0) {
+        hipDeviceProp_t prop;
+        k = -1;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) k = 1;
+        else (void)hipGetLastError();
+        known[dev].store(k, std::memory_order_relaxed);
+    }
+    return k == 1 ? TGRU_OK : TGRU_E_NOGPU;
 }
 
 // reserve: [L x 4 gate planes][(L-1) intermediate outputs][top output if layout != TBF]
@@ -158,7 +195,11 @@ RowMap id_map(const Dims &d) {
 
 extern "C" {
 
-int tgru_version(void) { return 100; }
+int tgru_version(void) { return 200; }
+
+unsigned long long tgru_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
+void tgru_reload_switches(void) { switches().read(); }
 
 const char *tgru_error_string(int code) {
     switch (code) {
@@ -244,7 +285,7 @@ static int check_forward(const tgru_forward_args &c) {
             return TGRU_E_ALIGN;
     }
     if (c.h0 && !aligned16(c.h0)) return TGRU_E_ALIGN;
-    return TGRU_OK;
+    return device_ok();
 }
 
 // arguments of the whole-stack forward kernels for one call
@@ -362,7 +403,7 @@ static int check_backward(const tgru_backward_args &c) {
     }
     if ((c.h0 && !aligned16(c.h0)) || (c.dh_n && !aligned16(c.dh_n)) || (c.dh0 && !aligned16(c.dh0)))
         return TGRU_E_ALIGN;
-    return TGRU_OK;
+    return device_ok();
 }
 
 // arguments of the whole-stack backward kernels (b) and of the weight-gradient stage (g) for one call;

@@ -2,8 +2,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace tgru {
+
+// Process-wide count of the kernel launches the library has issued (diagnostics only: a caller reads it
+// before and after a step to learn how many launches the step cost).
+extern std::atomic<unsigned long long> g_launches;
+#define TGRU_LAUNCH(...)                                                 \
+    do {                                                                 \
+        ::tgru::g_launches.fetch_add(1, std::memory_order_relaxed);      \
+        hipLaunchKernelGGL(__VA_ARGS__);                                 \
+    } while (0)
+
+// Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
+// them again.
+struct Switches {
+    bool force_generic, no_vec, no_mid, no_step, no_h24, gemm_guarded;
+    void read();
+    Switches() { read(); }
+};
+Switches &switches();
 
 // ----------------------------------------------------------------------------------------------
 // Row addressing.  Inside the library every per-(b,t) buffer is time-major: row = t*B + b.

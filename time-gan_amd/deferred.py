@@ -40,12 +40,18 @@ class _Queue:
         """Called by a backward function for the parameters it is about to produce gradients for.
         Only a parameter's FIRST gradient of the pass may be deferred (autograd just stores it); a later
         one is added to it, so the first must be complete by then -- pending work is flushed -- and the
-        later one is reduced at once."""
+        later one is reduced at once.  The same holds for a parameter that already HAS a gradient when the
+        pass starts (gradient accumulation over several passes, zero_grad(set_to_none=False)): autograd adds
+        to it on arrival.  And with create_graph=True (grad mode on inside backward) autograd clones what it
+        receives at once.  Neither case is deferred."""
         ptrs = {w.data_ptr() for w in weights}
         if len(ptrs) != len(weights) or not self.pending.isdisjoint(ptrs):
             self.flush()
         first = self.seen.isdisjoint(ptrs) and len(ptrs) == len(weights)
         self.seen |= ptrs
+        if first and (torch.is_grad_enabled() or any(w.grad is not None for w in weights)):
+            self.flush()
+            return False
         return first
 
     def add(self, fn, args_struct, keep, weights, device):

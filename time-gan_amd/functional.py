@@ -41,6 +41,14 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
+def _dense16(t: torch.Tensor) -> torch.Tensor:
+    """`t` as a dense tensor whose storage starts on a 16-byte boundary, which the library requires of every
+    buffer.  A contiguous slice of a larger tensor (x[1:], a rank's shard of a batch) is dense but may start
+    anywhere: it is copied then."""
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t
+
+
 def _stream(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -75,17 +83,19 @@ class _GRUFunction(torch.autograd.Function):
     """y, h_n = GRU(x, h0) with lengths; saves the library's reserve buffer for backward."""
 
     @staticmethod
-    def forward(ctx, x, h0, lengths, toff, B, T, layout, *weights):
+    def forward(ctx, x, h0, lengths, toff, B, T, layout, grad_mode, *weights):
         _require_gpu(x, "input")
         In, H, L = _dims(x, layout, B, T, weights)
-        x = x.contiguous()
-        weights = tuple(w.contiguous() for w in weights)
+        x = _dense16(x)
+        weights = tuple(_dense16(w) for w in weights)
         for w in weights:
             _require_gpu(w, "weight")
-        h0c = None if h0 is None else h0.contiguous()
+        h0c = None if h0 is None else _dense16(h0)
         w_ih, w_hh, b_ih, b_hh = _split_weights(weights, L)
         dev = x.device
-        need_grad = any(ctx.needs_input_grad)
+        # `grad_mode` is torch.is_grad_enabled() of the CALLER (inside forward() it is always off);
+        # needs_input_grad alone is also true under torch.no_grad(), where nothing must be saved
+        need_grad = grad_mode and any(ctx.needs_input_grad)
         with on_device(dev):
             lb = lib()
             y = torch.empty(x.shape[:-1] + (H,), device=dev, dtype=torch.float32)
@@ -114,8 +124,8 @@ class _GRUFunction(torch.autograd.Function):
         B, T, In, H, L, layout = ctx.dims
         x, h0, y, lengths, toff, reserve, *weights = ctx.saved_tensors
         dev = x.device
-        dy = torch.zeros_like(y) if dy is None else dy.contiguous()   # only h_n was used
-        dh_n = None if dh_n is None else dh_n.contiguous()
+        dy = torch.zeros_like(y) if dy is None else _dense16(dy)   # None: only h_n was used
+        dh_n = None if dh_n is None else _dense16(dh_n)
         with on_device(dev):
             lb = lib()
             ws = torch.empty(lb.tgru_backward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
@@ -138,13 +148,13 @@ class _GRUFunction(torch.autograd.Function):
             check(rc, "tgru_backward")
             if defer:
                 queue.add(lb.tgru_backward_reduce_jobs, args, [ws, arrays, flat], weights, dev)
-        return (dx, dh0, None, None, None, None, None, *grads)
+        return (dx, dh0, None, None, None, None, None, None, *grads)
 
 
 class _GRUPairFunction(torch.autograd.Function):
     """(yA, h_nA, yB, h_nB) = two independent GRU calls through tgru_forward_pair / tgru_backward_pair:
     when both run on the one-sequence-per-workgroup kernels they share one launch forward and one
-    backward (the two stacks run side by side on the GPU).  `specs` = ((B, T, layout), (B, T, layout));
+    backward (the two stacks run side by side on the GPU).  `specs` = ((B, T, layout), (B, T, layout), grad mode of the caller);
     `tensors` = x, h0, lengths, toff, *weights of call A, then the same of call B."""
 
     @staticmethod
@@ -153,14 +163,14 @@ class _GRUPairFunction(torch.autograd.Function):
         calls = []
         for k in range(2):
             x, h0, lengths, toff, *weights = tensors[k * (4 + nw):(k + 1) * (4 + nw)]
-            B, T, layout = specs[k]
+            B, T, layout = specs[k]      # (specs[2] is the caller's grad mode)
             _require_gpu(x, "input")
             In, H, L = _dims(x, layout, B, T, weights)
-            calls.append(dict(x=x.contiguous(), h0=None if h0 is None else h0.contiguous(), lengths=lengths,
-                              toff=toff, weights=tuple(w.contiguous() for w in weights), B=B, T=T, In=In, H=H,
+            calls.append(dict(x=_dense16(x), h0=None if h0 is None else _dense16(h0), lengths=lengths,
+                              toff=toff, weights=tuple(_dense16(w) for w in weights), B=B, T=T, In=In, H=H,
                               L=L, layout=layout))
         dev = calls[0]["x"].device
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = specs[2] and any(ctx.needs_input_grad)     # specs[2]: the caller's grad mode
         keep, args = [], []
         with on_device(dev):
             lb = lib()
@@ -206,8 +216,8 @@ class _GRUPairFunction(torch.autograd.Function):
                 x, h0, y, lengths, toff, reserve, *weights = saved[k * (6 + nw):(k + 1) * (6 + nw)]
                 B, T, In, H, L, layout, has_h0 = ctx.meta[k]
                 dy, dh_n = douts[2 * k], douts[2 * k + 1]
-                dy = torch.zeros_like(y) if dy is None else dy.contiguous()
-                dh_n = None if dh_n is None else dh_n.contiguous()
+                dy = torch.zeros_like(y) if dy is None else _dense16(dy)
+                dh_n = None if dh_n is None else _dense16(dh_n)
                 base = 1 + k * (4 + nw)          # position of this call's x among the forward inputs
                 ws = torch.empty(lb.tgru_backward_workspace_bytes(B, T, In, H, L) // 4, device=dev,
                                  dtype=torch.float32)
@@ -241,7 +251,7 @@ def gru_apply_pair(call_a, call_b):
     for x, weights, B, T, layout, h0, lengths, toff in (call_a, call_b):
         specs.append((B, T, layout))
         tensors += [x, h0, lengths, toff, *weights]
-    ya, ha, yb, hb = _GRUPairFunction.apply(tuple(specs), *tensors)
+    ya, ha, yb, hb = _GRUPairFunction.apply((specs[0], specs[1], torch.is_grad_enabled()), *tensors)
     return (ya, ha), (yb, hb)
 
 
@@ -255,7 +265,7 @@ def gru_apply(x: torch.Tensor, weights: Sequence[torch.Tensor], B: int, T: int, 
     lengths / toff: int32 device tensors (see include/tgru.h), None for full-length sequences.
     Returns (y in the same layout, h_n (L,B,H)).
     """
-    return _GRUFunction.apply(x, h0, lengths, toff, B, T, layout, *weights)
+    return _GRUFunction.apply(x, h0, lengths, toff, B, T, layout, torch.is_grad_enabled(), *weights)
 
 
 def gru_forward_backward_raw(x, weights, B, T, layout, dy, h0=None, dh_n=None, lengths=None, toff=None,

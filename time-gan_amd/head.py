@@ -82,13 +82,15 @@ class _HeadFunction(torch.autograd.Function):
         return (dx, None, dg0, db0, dw1, dc1, dg1, db1, dw2, dc2)
 
 
-def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear]) -> bool:
+def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear], lns=()) -> bool:
     """True when the fused kernels cover this head: GPU fp32 rows, input / output at most 32 wide, the
     middle (between the two Linears) at most 64, biases present."""
     if not x.is_cuda or x.dtype != torch.float32:
         return False
     if lin1.bias is None or (lin2 is not None and lin2.bias is None):
         return False
+    if any(ln is not None and (ln.weight is None or ln.bias is None) for ln in lns):
+        return False      # LayerNorm(elementwise_affine=False): the fused kernels expect gamma and beta
     if lin1.in_features > MAX_IO_WIDTH:
         return False
     if lin2 is None:
@@ -101,7 +103,7 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
     """lin2(relu(ln1(lin1(ln0(x))))) with the optional stages as given; torch modules when the fused
     kernels do not cover the widths (still on the GPU)."""
     assert (ln1 is None) == (lin2 is None)
-    if not supported(x, lin1, lin2):
+    if not supported(x, lin1, lin2, (ln0, ln1)):
         h = wide_linear(x if ln0 is None else wide_layer_norm(x, ln0), lin1)
         return h if lin2 is None else wide_linear(torch.relu(wide_layer_norm(h, ln1)), lin2)
     eps = (ln0 or ln1).eps if (ln0 is not None or ln1 is not None) else 1e-5
@@ -307,7 +309,7 @@ def _eps_of(ln0, ln1):
 def head_apply_pair(x_a: torch.Tensor, spec_a, x_b: torch.Tensor, spec_b):
     """(head_apply(x_a, *spec_a), head_apply(x_b, *spec_b)) for two independent heads, in one launch when
     the fused kernels cover both; spec = (ln0, lin1, ln1, lin2) as for head_apply."""
-    ok = all(supported(x, spec[1], spec[3]) for x, spec in ((x_a, spec_a), (x_b, spec_b)))
+    ok = all(supported(x, spec[1], spec[3], (spec[0], spec[2])) for x, spec in ((x_a, spec_a), (x_b, spec_b)))
     if not ok or x_a.device != x_b.device:
         return head_apply(x_a, *spec_a), head_apply(x_b, *spec_b)
     for spec in (spec_a, spec_b):

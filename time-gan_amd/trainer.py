@@ -138,6 +138,23 @@ class TimeGANTrainer:
             for p in params:
                 p.grad = None
 
+    def reset_optimizers(self) -> None:
+        """Adam state (moment estimates, step counters) of all six optimisers back to zero, in place -- the
+        state a freshly built optimiser has.  The reference runs ONE phase per time_gan_trainer() call with
+        newly built optimisers (TimeGANv1.py:932-938) and hands only state_dicts of the networks from phase
+        to phase (:951-1009)."""
+        for opt in self.opt.values():
+            for st in opt.state.values():
+                for k in ("exp_avg", "exp_avg_sq", "step"):
+                    v = st.get(k)
+                    if isinstance(v, torch.Tensor):
+                        v.zero_()
+                    elif v is not None:
+                        st[k] = 0
+        if self.device.type != "cuda":          # torch's own step() re-creates state that is absent
+            for opt in self.opt.values():
+                opt.state.clear()
+
     def _sync_grads(self, *names):
         all_reduce_grads([self.nets[k] for k in names], group=self.group)
 
@@ -354,14 +371,16 @@ class TimeGANTrainer:
 
     # -- the three phases over a dataset (TimeGANv1.py:573-812 loops, :940-1009 driver) ---------------
     def fit(self, dataset, phases: Sequence[str] = ("embedding", "supervisor", "joint"), batch_size: Optional[int] = None,
-            seed: int = 0, on_batch=None) -> Dict[str, List]:
+            seed: int = 0, on_batch=None, fresh_optimizers: bool = True) -> Dict[str, List]:
         """Runs the named phases in order, each for its configured number of epochs
         (cfg['emb']['num_epochs'], cfg['sup']['num_epochs'], cfg['system']['jointly_num_epochs'],
         TimeGANv1.py:581,658,745) over `dataset` (data.ResidentDataset, or anything with the same
         `batches(batch_size, shuffle, generator, rank, world)`); `batch_size` is the GLOBAL batch, of which
         every rank of the group takes its shard.  Returns the per-batch losses of each phase.
         `on_batch(phase, epoch, index, result)` is called after every batch (logging hooks, early stops by
-        raising StopIteration)."""
+        raising StopIteration).  `fresh_optimizers` (default): every phase starts from zeroed Adam state, as
+        in the reference, where each phase is a run of its own with newly built optimisers
+        (TimeGANv1.py:932-938); False carries the moment estimates of `rec` and `sup` into the joint phase."""
         from .parallel import rank as rank_of, world_size
         bs = int(batch_size if batch_size is not None else self.cfg["system"]["batch_size"])
         epochs = {"embedding": int(self.cfg["emb"]["num_epochs"]), "supervisor": int(self.cfg["sup"]["num_epochs"]),
@@ -375,6 +394,8 @@ class TimeGANTrainer:
                 if phase not in steps:
                     raise ValueError("The step should be: embedding, supervisor or joint")   # TimeGANv1.py:1012
                 log = history.setdefault(phase, [])
+                if fresh_optimizers:
+                    self.reset_optimizers()
                 for epoch in range(epochs[phase]):
                     for i, x in enumerate(dataset.batches(bs, shuffle=True, generator=gen, rank=r, world=w)):
                         out = steps[phase](x)
