@@ -53,7 +53,8 @@ enum {
     TGRU_E_LAYOUT = -3,    /* unknown layout, or PACKED without lengths / toff */
     TGRU_E_ALIGN = -4,     /* a buffer is not 16-byte aligned */
     TGRU_E_LAUNCH = -5,    /* a kernel launch failed; hipGetLastError() has the cause */
-    TGRU_E_NOGPU = -6      /* the current device is not a gfx950 GPU */
+    TGRU_E_NOGPU = -6,     /* the current device is not a gfx950 GPU */
+    TGRU_E_TOOBIG = -7     /* tgru_forward_static: the call needs more than TGRU_STATIC_WORKSPACE_BYTES */
 };
 
 /* Library version (major*10000 + minor*100 + patch).  No reference counterpart. */
@@ -106,6 +107,28 @@ int tgru_forward(const float *x, const float *h0,
                  float *y, float *h_n, float *reserve, float *workspace,
                  int B, int T, int In, int H, int L, int layout,
                  tgru_stream_t stream);
+
+/*
+ * tgru_forward for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops (generation / scoring), harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * Same arguments and results as tgru_forward, but no `workspace`: the scratch memory (input projections,
+ * packed W_hh, intermediate layer outputs) is a fixed array of TGRU_STATIC_WORKSPACE_BYTES inside the
+ * library, one copy on every GPU the library runs on, held until the process ends.  The call allocates and
+ * frees nothing.  A call that needs more (tgru_forward_workspace_bytes(B, T, In, H, L) >
+ * TGRU_STATIC_WORKSPACE_BYTES) returns TGRU_E_TOOBIG and launches nothing.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads) race on it; calls on one stream are ordered and safe.  Nothing in the array has to be cleared
+ * between calls (every float is written before it is read within a call).  The first call on a device
+ * looks up the array's address there; make it outside graph capture.
+ */
+#define TGRU_STATIC_WORKSPACE_BYTES (64u << 20)
+int tgru_forward_static(const float *x, const float *h0,
+                        const int32_t *lengths, const int32_t *toff,
+                        const float *const *w_ih, const float *const *w_hh,
+                        const float *const *b_ih, const float *const *b_hh,
+                        float *y, float *h_n, float *reserve,
+                        int B, int T, int In, int H, int L, int layout,
+                        tgru_stream_t stream);
 
 /*
  * Backprop-through-time of tgru_forward.  Replaces the autograd graph torch records under

@@ -42,7 +42,7 @@ def test_size_queries_and_error_strings():
     assert lb.tgru_reserve_bytes(0, T, In, H, L, 0) == 0            # bad dims -> 0
     assert lb.tgru_reserve_bytes(B, T, In, 4096, L, 0) == 0         # hidden size beyond the built range
     assert lb.tgru_error_string(0) == b"ok"
-    for code in range(-6, 0):
+    for code in range(-7, 0):
         assert lb.tgru_error_string(code) not in (b"ok", b"unknown error")
     # NULL pointers are rejected before anything is launched
     rc = lb.tgru_forward(None, None, None, None, None, None, None, None, None, None, None, None,

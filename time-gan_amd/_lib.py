@@ -57,6 +57,7 @@ class AdamJob(ctypes.Structure):
 MAX_ADAM_JOBS = 64        # TGRU_MAX_ADAM_JOBS
 MAX_ADAM_ELEMS = 16384    # TGRU_MAX_ADAM_ELEMS
 DEFER_REDUCE = 2          # TGRU_DEFER_REDUCE
+STATIC_WORKSPACE_BYTES = 64 << 20   # TGRU_STATIC_WORKSPACE_BYTES
 MAX_JOBS_PER_CALL = 32    # upper bound of jobs one backward call can owe (5 per layer, at most 4 layers on that path)
 
 # name -> (restype, argtypes); mirrors include/tgru.h one to one
@@ -69,6 +70,7 @@ SIGNATURES = {
     "tgru_forward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
     "tgru_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
     "tgru_forward": (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
+    "tgru_forward_static": (_i, [_vp] * 11 + [_i] * 6 + [_vp]),
     "tgru_backward": (_i, [_vp] * 19 + [_i] * 7 + [_vp]),
     "tgru_forward_pair": (_i, [ctypes.POINTER(ForwardArgs)] * 2 + [_vp]),
     "tgru_backward_pair": (_i, [ctypes.POINTER(BackwardArgs)] * 2 + [_vp]),

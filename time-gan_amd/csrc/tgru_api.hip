@@ -186,6 +186,35 @@ RowMap id_map(const Dims &d) {
     return m;
 }
 
+// Scratch memory of tgru_forward_static: an array inside the library's code object, one copy per GPU at
+// its own address.  `scratch` itself is only a host-side handle: its device address is looked up once per
+// device with hipGetSymbolAddress and every use goes through that pointer.
+constexpr size_t kStaticFloats = TGRU_STATIC_WORKSPACE_BYTES / sizeof(float);
+static __device__ __align__(256) float scratch[kStaticFloats];
+
+int static_workspace(float **out) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<float *> ptr[kMaxDev];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        (void)hipGetLastError();
+        return TGRU_E_NOGPU;
+    }
+    float *p = ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        // first call on this device (which is current): resolve this GPU's copy of the array
+        void *sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym) {
+            (void)hipGetLastError();
+            return TGRU_E_LAUNCH;
+        }
+        p = static_cast<float *>(sym);
+        ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return TGRU_OK;
+}
+
 #define TGRU_HIP(expr)                                   \
     do {                                                 \
         if ((expr) != hipSuccess) return TGRU_E_LAUNCH;  \
@@ -210,6 +239,8 @@ const char *tgru_error_string(int code) {
     case TGRU_E_ALIGN: return "a buffer is not 16-byte aligned";
     case TGRU_E_LAUNCH: return "a kernel launch failed";
     case TGRU_E_NOGPU: return "the current device is not a gfx950 GPU";
+    case TGRU_E_TOOBIG: return "the call needs more scratch memory than tgru_forward_static holds "
+                               "(TGRU_STATIC_WORKSPACE_BYTES); use tgru_forward with a workspace";
     default: return "unknown error";
     }
 }
@@ -360,6 +391,26 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         in = f.y_int;
     }
     return TGRU_OK;
+}
+
+int tgru_forward_static(const float *x, const float *h0, const int32_t *lengths, const int32_t *toff,
+                        const float *const *w_ih, const float *const *w_hh, const float *const *b_ih,
+                        const float *const *b_hh, float *y, float *h_n, float *reserve, int B, int T, int In,
+                        int H, int L, int layout, tgru_stream_t stream) {
+    // the argument checks of tgru_forward first (with a stand-in for the workspace pointer), then the size
+    float *const standin = reinterpret_cast<float *>(uintptr_t(256));
+    const tgru_forward_args c{x, h0, lengths, toff, w_ih, w_hh, b_ih, b_hh, y, h_n, reserve, standin,
+                              B, T, In, H, L, layout};
+    int rc = check_forward(c);
+    if (rc != TGRU_OK) return rc;
+    const Dims d{B, T, In, H, L, layout};
+    if (fwd_ws_floats(d) > kStaticFloats) return TGRU_E_TOOBIG;
+    float *ws = nullptr;
+    rc = static_workspace(&ws);
+    if (rc != TGRU_OK) return rc;
+    // nothing in the forward workspace has to start at zero: every float is written before it is read
+    return tgru_forward(x, h0, lengths, toff, w_ih, w_hh, b_ih, b_hh, y, h_n, reserve, ws, B, T, In, H, L,
+                        layout, stream);
 }
 
 static bool pair_on_vec(int B0, int T0, int In0, int H0, int L0, int lay0, int B1, int T1, int In1, int H1, int L1,
