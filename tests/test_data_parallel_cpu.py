@@ -28,8 +28,8 @@ def _make_trainer(group=None):
 
 def _data():
     g = torch.Generator().manual_seed(9)
-    x = torch.rand(6, 8, 5, generator=g)           # uneven shards: 3 + 3 with world 2; 6 = global batch
-    noise = [torch.rand(6, 8, 5, generator=g) for _ in range(11)]
+    x = torch.rand(7, 8, 5, generator=g)           # global batch 7: shards 4 + 3 (world 2), 2 + 2 + 2 + 1 (world 4)
+    noise = [torch.rand(7, 8, 5, generator=g) for _ in range(11)]
     return x, noise
 
 
@@ -74,7 +74,8 @@ def _worker(rank, world, port, path):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_match_single_process(tmp_path, world):
     torch.set_num_threads(1)
     tr = _make_trainer()
     x, noise = _data()
@@ -83,7 +84,7 @@ def test_two_ranks_match_single_process(tmp_path):
     ref_sd = tr.state_dicts()
 
     path = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), path), nprocs=world, join=True)
     got = torch.load(path, weights_only=False)
 
     # exactness of the sharded loss and of the rank-summed gradients, before Adam amplifies anything
@@ -157,23 +158,39 @@ def test_sharded_generation_and_scores_match_single_process(tmp_path):
     assert abs(got["p"] - p) <= 1e-4 * abs(p) + 1e-6
 
 
-def _fit_small(group=None):
-    """fit() over a small resident dataset whose last global batch is ragged (11 windows, batches of 4)."""
+class _DropShortBatches:
+    """What a single process must see to mirror `world` ranks: a global batch with fewer rows than ranks is
+    dropped by every rank (data.ResidentDataset.batches), so it is dropped here too."""
+
+    def __init__(self, ds, world):
+        self.ds, self.world = ds, world
+
+    def batches(self, batch_size, shuffle=True, generator=None, rank=0, world=1):
+        for b in self.ds.batches(batch_size, shuffle=shuffle, generator=generator):
+            if b.shape[0] >= self.world:
+                yield b
+
+
+def _fit_small(group=None, phases=("embedding", "supervisor"), mirror_world=1):
+    """fit() over a small resident dataset whose last global batch is ragged (11 windows, batches of 4:
+    4 + 4 + 3)."""
     import timegan_amd as tg
     tr = _make_trainer(group)
     tr.cfg["system"]["batch_size"] = 4
     data = np.random.default_rng(4).uniform(0, 1, (11, 8, 5)).astype(np.float32)
     ds = tg.data.ResidentDataset(data, "cpu")
-    hist = tr.fit(ds, phases=("embedding", "supervisor"), seed=6)
+    if mirror_world > 1:
+        ds = _DropShortBatches(ds, mirror_world)
+    hist = tr.fit(ds, phases=phases, seed=6)
     return hist, tr.state_dicts()
 
 
-def _fit_worker(rank, world, port, path):
+def _fit_worker(rank, world, port, path, phases=("embedding", "supervisor")):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    hist, sd = _fit_small(dist.group.WORLD)
+    hist, sd = _fit_small(dist.group.WORLD, phases)
     if rank == 0:
         torch.save({"hist": hist, "sd": sd}, path)
     dist.barrier()
@@ -194,3 +211,28 @@ def test_fit_over_a_sharded_dataset_matches_single_process(tmp_path):
     for net in ("emb", "rec", "sup"):
         for name, p in ref_sd[net].items():
             np.testing.assert_allclose(got["sd"][net][name].numpy(), p.numpy(), rtol=5e-3, atol=5e-4, err_msg=f"{net}.{name}")
+
+
+def test_fit_with_more_ranks_than_rows_in_the_tail_batch_and_the_joint_phase(tmp_path):
+    """World size 4 over global batches of 4 + 4 + 3 windows: every rank holds ONE window of a full batch,
+    the 3-window tail has fewer rows than ranks and is dropped by all of them alike, and all three phases
+    (the joint phase with its rank-consistent discriminator branch included) follow the single-process run
+    over the same batches."""
+    torch.set_num_threads(1)
+    phases = ("embedding", "supervisor", "joint")
+    ref_hist, ref_sd = _fit_small(phases=phases, mirror_world=4)
+    path = str(tmp_path / "fit4.pt")
+    mp.spawn(_fit_worker, args=(4, _free_port(), path, phases), nprocs=4, join=True)
+    got = torch.load(path, weights_only=False)
+    for phase in ("embedding", "supervisor"):
+        assert len(got["hist"][phase]) == len(ref_hist[phase]) == 2
+        np.testing.assert_allclose(got["hist"][phase], ref_hist[phase], rtol=2e-3)
+    assert len(got["hist"]["joint"]) == len(ref_hist["joint"]) == 2
+    for a, b in zip(got["hist"]["joint"], ref_hist["joint"]):
+        assert a["d_stepped"] == b["d_stepped"]
+        np.testing.assert_allclose(a["g_loss"], b["g_loss"], rtol=5e-3)
+        np.testing.assert_allclose(a["e_loss"], b["e_loss"], rtol=5e-3)
+        np.testing.assert_allclose(a["d_loss"], b["d_loss"], rtol=5e-3)
+    for net in ("emb", "rec", "sup", "g", "d"):
+        for name, p in ref_sd[net].items():
+            np.testing.assert_allclose(got["sd"][net][name].numpy(), p.numpy(), rtol=1e-2, atol=2e-3, err_msg=f"{net}.{name}")

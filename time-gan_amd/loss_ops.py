@@ -11,10 +11,9 @@ import ctypes
 from typing import Optional, Sequence, Tuple
 
 import torch
-import torch.distributed as dist
 
 from ._lib import check, lib, on_device
-from .parallel import multi_rank
+from .parallel import _all_reduce_sum, multi_rank
 
 EMBED_SIDE, SUPERVISOR, EMBED_MAIN, DISCRIMINATOR, GENERATOR = range(5)
 
@@ -60,10 +59,10 @@ class _LossFunction(torch.autograd.Function):
                 check(lb.tgru_loss_partial(kind, 0, inp, B, T, H, F, bp, st), "tgru_loss_partial")
             else:
                 check(lb.tgru_loss_partial(kind, 1, inp, B, T, H, F, bp, st), "tgru_loss_partial")
-                dist.all_reduce(buf[:n_a], group=group)
+                _all_reduce_sum(buf[:n_a], group)
                 if n_b:
                     check(lb.tgru_loss_partial(kind, 2, inp, B, T, H, F, bp, _stream(dev)), "tgru_loss_partial")
-                    dist.all_reduce(buf[n_a:n_a + n_b], group=group)
+                    _all_reduce_sum(buf[n_a:n_a + n_b], group)
             check(lb.tgru_loss_final(kind, B, T, H, F, float(gamma), bp, _stream(dev)), "tgru_loss_final")
         ctx.meta = (kind, dims, float(gamma))
         ctx.save_for_backward(buf, *tensors)

@@ -32,6 +32,23 @@ def rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
+def _staged(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory: a device tensor handed to it is staged by the backend itself, one transfer
+    per call and -- when several ranks share one GPU, as in rehearsals of the multi-rank flow on a one-GPU
+    box -- prone to stalls.  Device tensors are therefore staged through the host here, explicitly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    """In-place SUM over the ranks of `group` (RCCL takes the device tensor as it is)."""
+    if _staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class _DistSum(torch.autograd.Function):
     """S = sum over ranks of s_r.  Contract: every rank computes the SAME function of S afterwards
     (replicated arithmetic only), so dL/ds_r = dL/dS is available locally and the backward is the
@@ -41,7 +58,7 @@ class _DistSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         out = x.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(out, group)
         return out
 
     @staticmethod
@@ -63,7 +80,7 @@ def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
     if not params:
         return 0
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(flat, group)
     views, off = [], 0
     for p in params:
         n = p.numel()
@@ -74,11 +91,27 @@ def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
 
 
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:
+    """Parameters and buffers of `modules` from rank `src` to every rank: ONE flat buffer (one collective)
+    per network and dtype, not one broadcast per tensor."""
     if not multi_rank(group):
         return
     for m in modules:
+        by_dtype = {}
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            by_dtype.setdefault(t.dtype, []).append(t.data)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            if _staged(flat, group):
+                c = flat.cpu()
+                dist.broadcast(c, src=src, group=group)
+                flat.copy_(c)
+            else:
+                dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
 
 
 def shard_batch(x: torch.Tensor, group=None) -> torch.Tensor:
@@ -98,6 +131,21 @@ def shard_bounds(n: int, group=None):
     base, rem = divmod(n, w)
     start = r * base + min(r, rem)
     return start, start + base + (1 if r < rem else 0)
+
+
+def shard_extent(n_local: int, device, group=None):
+    """(start, stop, total) of this rank's rows inside the concatenation of all ranks' shards, from the
+    shard sizes themselves (one small all-gather): works for any split, even or not."""
+    if not multi_rank(group):
+        return 0, n_local, n_local
+    w, r = world_size(group), rank(group)
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(w)]
+    dist.all_gather(parts, mine, group=group)
+    sizes = [int(p.item()) for p in parts]
+    start = sum(sizes[:r])
+    return start, start + n_local, sum(sizes)
 
 
 def all_gather_rows(x_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:

@@ -16,7 +16,8 @@ from .modules import build_networks
 from .optim import AdamStep, init_adam_state
 import torch.distributed as dist
 
-from .parallel import all_gather_rows, all_reduce_grads, broadcast_parameters, multi_rank, shard_batch
+from .parallel import (all_gather_rows, all_reduce_grads, broadcast_parameters, multi_rank, shard_batch,
+                       shard_extent)
 
 
 class _GraphedStep:
@@ -158,6 +159,19 @@ class TimeGANTrainer:
     def _sync_grads(self, *names):
         all_reduce_grads([self.nets[k] for k in names], group=self.group)
 
+    def _noise_like(self, x: torch.Tensor, count: int) -> List[torch.Tensor]:
+        """`count` noise tensors shaped like x, U[0,1) as torch.rand_like(x) draws them
+        (TimeGANv1.py:762,793).  With several ranks, x is this rank's shard of a global batch: every rank
+        draws the noise of the WHOLE batch from its (identically seeded) generator and keeps the rows of its
+        shard, so the ranks use different rows of one stream -- the rows a single process would have drawn
+        for the concatenated batch.  (Identically seeded ranks drawing rand_like(shard) would all get the
+        same rows: a generated batch of duplicates, whose batch statistics degenerate.)"""
+        if not multi_rank(self.group):
+            return [torch.rand_like(x) for _ in range(count)]
+        lo, hi, total = shard_extent(int(x.shape[0]), x.device, self.group)
+        shape = (total,) + tuple(x.shape[1:])
+        return [torch.rand(shape, device=x.device, dtype=x.dtype)[lo:hi].contiguous() for _ in range(count)]
+
     def lengths_of(self, x: torch.Tensor) -> List[int]:
         """What Energy.extract_time returns for a batch (data/Energy.py:12-19): every length = T."""
         return [x.shape[1]] * x.shape[0]
@@ -280,6 +294,8 @@ class TimeGANTrainer:
             zb = self._bufs.get("z11")
             if zb is None or zb.shape[1:] != x.shape:
                 zb = self._bufs["z11"] = torch.empty((11,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+            if noise is None and multi_rank(self.group):
+                noise = self._noise_like(x, 11)
             if noise is not None:
                 for i in range(11):
                     zb[i].copy_(noise[i])
@@ -292,8 +308,11 @@ class TimeGANTrainer:
             vals = torch.stack(list(outs)).tolist()           # one copy to the host for all 22 numbers
             return {"g_loss": vals[0:20:2], "e_loss": vals[1:20:2], "d_loss": vals[20], "d_stepped": vals[21] != 0.0}
 
+        if noise is None:
+            noise = self._noise_like(x, 11)
+
         def draw():
-            return noise.pop(0) if noise is not None else torch.rand_like(x)
+            return noise.pop(0)
         g_losses, e_losses = [], []
         for _ in range(10):
             z = draw()
@@ -318,10 +337,10 @@ class TimeGANTrainer:
 
     def _joint_step_with_lengths(self, x, t, noise):
         n = self.nets
-        noise = list(noise) if noise is not None else None
+        noise = list(noise) if noise is not None else self._noise_like(x, 11)
         out = {"g_loss": [], "e_loss": []}
         for _ in range(10):
-            z = noise.pop(0) if noise is not None else torch.rand_like(x)
+            z = noise.pop(0)
             self._zero("emb", "rec", "sup", "g", "d")
             g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
                                               group=self.group)
@@ -337,7 +356,7 @@ class TimeGANTrainer:
             out["e_loss"].append(float(e_loss.detach()))
             self._sync_grads("emb", "rec")
             self._step("emb_main", "rec")
-        z = noise.pop(0) if noise is not None else torch.rand_like(x)
+        z = noise.pop(0)
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z, group=self.group)
         stepped = bool(d_loss > self.d_threshold)
