@@ -135,14 +135,17 @@ def test_mid_hidden_with_initial_state_and_ragged_lengths():
             assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
-@pytest.mark.parametrize("per_step", [True, False])
-def test_large_hidden_with_initial_state_and_ragged_lengths(per_step, monkeypatch):
-    """H > 128 in multiples of 32 runs one launch per time step (128 sequences x 32 units per workgroup);
-    TGRU_NO_STEP=1 keeps the persistent 16-sequence kernels covered on the same cases."""
+@pytest.mark.parametrize("family", ["persistent_tiles", "launch_per_step", "sixteen_sequences"])
+def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch):
+    """H > 128 in multiples of 32 runs on 128-sequence x 32-unit tiles with the time loop inside the kernel
+    (the workgroups of a row tile synchronise through counters); TGRU_NO_PERSIST=1 gives the same tiles
+    with one launch per time step, TGRU_NO_STEP=1 the 16-sequence kernels: all three on the same cases."""
     import timegan_amd as tg
-    if per_step:
-        monkeypatch.delenv("TGRU_NO_STEP", raising=False)
-    else:
+    monkeypatch.delenv("TGRU_NO_STEP", raising=False)
+    monkeypatch.delenv("TGRU_NO_PERSIST", raising=False)
+    if family == "launch_per_step":
+        monkeypatch.setenv("TGRU_NO_PERSIST", "1")
+    elif family == "sixteen_sequences":
         monkeypatch.setenv("TGRU_NO_STEP", "1")
     tg.reload_switches()
     for (B, T, In, H, L, lens) in ((300, 5, 40, 160, 2, [5] * 100 + [4] * 50 + [2] * 100 + [1] * 50),
@@ -165,7 +168,7 @@ def test_large_hidden_with_initial_state_and_ragged_lengths(per_step, monkeypatc
         gh = torch.randn(hnr.shape, generator=torch.Generator().manual_seed(2))
         ((yr * gy).sum() + (hnr * gh).sum()).backward()
         ((yo * gy.cuda()).sum() + (hno * gh.cuda()).sum()).backward()
-        tag = f"B{B}H{H}{'step' if per_step else 'persistent'}"
+        tag = f"B{B}H{H} {family}"
         with torch.no_grad():   # inference: no reserve, the top layer's time-major copy lives in the workspace
             yi, _ = ours(x.cuda(), h0.cuda(), lengths=lens)
         assert_close(yi.cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " y (no_grad)")

@@ -213,6 +213,333 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwd s) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Persistent variants: the time loop INSIDE the kernel, same tiles.  A launch per step pays, at every
+// step, the drain of the step's stores, the kernel boundary (with the write-back of the L2) and the
+// first operand fetch from beyond the L2 -- about as long as the products themselves take.  But a row
+// tile (128 sequences) at step t only depends on the SAME row tile at step t-1: the H / 32 workgroups
+// that own its unit tiles.  So the workgroups stay resident for all steps and only the workgroups of one
+// row tile wait for each other, through a counter in device memory:
+//   * a workgroup stores its 128 x 32 tile of the new state with write-through (`sc1`) 16-byte stores,
+//     every wave waits for its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and one lane
+//     adds 1 to the row tile's counter (agent scope);
+//   * before the products of step t one lane polls the counter (write-through loads) until all unit tiles
+//     of step t-1 have arrived, the workgroup meets at a barrier, and the state tiles are fetched with
+//     `sc1` loads (they bypass the CU's L1; each 128-byte line is written whole by one store instruction).
+// Everything else a step needs from memory (its input projections, the saved gates) is requested BEFORE
+// the wait; the workgroup's own tile of the previous state / carry stays in registers.
+// All workgroups of a launch must be resident at once: the launcher gives a launch at most one workgroup
+// per CU (a second one does not fit beside the first: registers) and splits larger batches into several
+// launches.  Every wait is bounded: a workgroup that does not see its peers within kSpinLimit polls stops
+// waiting, so the grid always drains (the results are then wrong, and the error word is set).
+// ----------------------------------------------------------------------------------------------
+#ifdef TGRU_STAMPS   // diagnostic build only: time (100 MHz ticks) one wave of workgroup 0 spends per phase
+__device__ unsigned long long tgru_stamps_step[16];
+#define PSTAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PSTAMP(k)                                                     \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += now_ - st_last; st_last = now_;                  \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+#define PSTAMP_FLUSH(base)                                            \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                          \
+        for (int k_ = 0; k_ < 8; ++k_) tgru_stamps_step[(base) + k_] = st_acc[k_];
+extern "C" int tgru_debug_stamps_step(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgru_stamps_step), sizeof(unsigned long long) * 16);
+}
+#else
+#define PSTAMP_DECL
+#define PSTAMP(k)
+#define PSTAMP_FLUSH(base)
+#endif
+
+constexpr int kSpinLimit = 1 << 24;
+#ifndef TGRU_PERSIST_DEPTH
+#define TGRU_PERSIST_DEPTH 2
+#endif
+#ifndef TGRU_PERSIST_BK
+#define TGRU_PERSIST_BK 64
+#endif
+constexpr int kPersistBK = TGRU_PERSIST_BK;                       // k-tile of the persistent kernels
+constexpr int kPersistDepth = TGRU_PERSIST_DEPTH;    // operand tiles in flight ahead of the products (even)
+constexpr int kAuxSc1 = 16;   // cache policy bits of the raw buffer builtins: sc1 (write-through / L1 bypass)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+// descriptor of `bytes` bytes at p, or an empty one (loads give 0, stores are dropped) when p is null
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_opt(const void *p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, sbase, 0));
+}
+__device__ __forceinline__ void st1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, sbase, 0);
+}
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kAuxSc1);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float4 f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, kAuxSc1);
+}
+
+// One lane of the workgroup waits until `*cnt` has reached `want`; the others wait at the barrier.
+__device__ __forceinline__ void wait_for_peers(unsigned *cnt, unsigned want, unsigned *err) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// All stores of this workgroup issued so far are complete; then one lane tells the row tile's counter.
+__device__ __forceinline__ void arrive(unsigned *cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct PersistFwd {
+    FwdArgs f;
+    float *ybuf;          // (T*B, H) time-major buffer the states travel through (y_int, or a time-major y_ext)
+    unsigned *sync;       // sync[0]: error word; sync[1 + mt]: arrivals of row tile mt; all zero at launch
+    int mt0, MT, mtx;     // this launch serves row tiles [mt0, mt0 + MT)
+};
+
+template <int BK>      // k-tile: 64, or 32 when H is not a multiple of 64
+__global__ __launch_bounds__(256) void gru_persist_fwd_kernel(PersistFwd s) {
+    // Operand tiles sit in LDS as the global rows do, k contiguous (rows of BK floats + 4 of padding), so a
+    // tile is filled with one 16-byte write per 16-byte load and a lane fetches FOUR k-steps of an operand
+    // with one 16-byte read.  The reduction index of an MFMA step may be permuted freely as long as both
+    // operands agree: step j of chunk q stands for k = 8q + 4*(lane >> 5) + j for A and B alike.
+    constexpr int BN = 3 * kUnits, LDK = BK + 4, LDH = kUnits + 4;
+    // one LDS array: the operand tiles of the products, and -- once the products of a step are done -- the
+    // new state tile on its way out
+    __shared__ __attribute__((aligned(16))) float lds[2 * (kRows + BN) * LDK];
+    static_assert(kRows * LDH <= 2 * (kRows + BN) * LDK, "state tile fits over the operand tiles");
+    float (*As)[kRows][LDK] = reinterpret_cast<float (*)[kRows][LDK]>(lds);
+    float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(lds + 2 * kRows * LDK);
+    float (*Hs)[LDH] = reinterpret_cast<float (*)[LDH]>(lds);
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const FwdArgs &a = s.f;
+    const int H = a.H, B = a.B, T = a.T, NT = H / kUnits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int m0 = mt * kRows, u0 = nt * kUnits;
+    const int u = u0 + lrow;
+    unsigned *cnt = s.sync + 1 + mt;
+    const long plane = (long)T * B * H;
+    const long step_bytes = (long)B * H * 4;
+
+    int lenv[16];
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wave + d_row(r, lk);
+        const int mc = min(m, B - 1);
+        lenv[r] = a.lengths ? a.lengths[mc] : T;
+        valid |= (m < B ? 1u : 0u) << r;
+    }
+    // byte offset of (sequence of register r, unit u) inside one step's (B, H) block; every per-step
+    // operand is addressed as descriptor(step) + this offset, rows past the batch clamped to the last one
+    int roff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wave + d_row(r, lk), B - 1) * H + u) * 4;
+    const float b_r = a.b_hh[u], b_z = a.b_hh[H + u], b_n = a.b_hh[2 * H + u];
+    float hp[16];      // this workgroup's own tile of the state entering the step
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mc = min(m0 + 32 * wave + d_row(r, lk), B - 1);
+        hp[r] = a.h0 ? a.h0[(long)mc * H + u] : 0.f;
+    }
+
+    // tile slots (one float4 each): A kRows x BK/4, B 96 x BK/4 (rows of W_hh: gate*H + u0 + j); no load is
+    // conditional: rows past the batch are clamped (their results are never stored), spare W_hh slots
+    // re-read a valid row
+    constexpr int KQ = BK / 4, PA = kRows * KQ / 256, PB = (BN * KQ + 255) / 256;
+    int a_off[PA], b_off[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+        a_off[p] = (min(m0 + row, B - 1) * H + kc) * 4;       // bytes inside one step's (B, H) block
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int slot = min(tid + p * 256, BN * KQ - 1), row = slot / KQ, kc = (slot % KQ) << 2;
+        b_off[p] = ((row >> 5) * H + u0 + (row & 31)) * H + kc;
+    }
+    struct Regs { float4 a[PA], b[PB]; };
+    const int nkt = H / BK;
+    PSTAMP_DECL
+
+    for (int t = 0; t < T; ++t) {
+        PSTAMP(7);
+        // operands of the epilogue, requested before the wait and the products
+        float gir[16], giz[16], gin[16];
+        {
+            const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(a.gi + (long)t * B * 3 * H, 3 * step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {      // row m of gi is 3H wide: 3 * (m * H) + u
+                const int o = 3 * roff[r] - 8 * u;
+                gir[r] = ld1(rs_gi, o, 0);
+                giz[r] = ld1(rs_gi, o, H * 4);
+                gin[r] = ld1(rs_gi, o, 2 * H * 4);
+            }
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+        const bool have_state = t > 0 || a.h0 != nullptr;
+        PSTAMP(0);
+        if (t > 0) wait_for_peers(cnt, (unsigned)(NT * t), s.sync);
+        PSTAMP(1);
+        if (have_state) {
+            const __amdgpu_buffer_rsrc_t rs_h =
+                rsrc_of(t > 0 ? s.ybuf + (long)(t - 1) * B * H : a.h0, step_bytes);
+            auto load_tiles = [&](int k0, Regs &g) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p) g.a[p] = ld4_sc1(rs_h, a_off[p] + k0 * 4);
+#pragma unroll
+                for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(a.w_hh + b_off[p] + k0);
+            };
+            auto store_tiles = [&](int buf, const Regs &g) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+                    *reinterpret_cast<float4 *>(&As[buf][row][kc]) = g.a[p];
+                }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+                    if (slot < BN * KQ) *reinterpret_cast<float4 *>(&Bs[buf][row][kc]) = g.b[p];
+                }
+            };
+            constexpr int kDepth = kPersistDepth;
+            Regs ring[kDepth];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) load_tiles(min(d, nkt - 1) * BK, ring[d]);
+            store_tiles(0, ring[0]);
+            load_tiles(min(kDepth, nkt - 1) * BK, ring[0]);
+            __syncthreads();
+            PSTAMP(2);
+            for (int kt0 = 0; kt0 < nkt; kt0 += kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int kt = kt0 + d, cur = kt & 1;
+                    if (kt < nkt) {
+                        auto product = [&](int q) {      // chunk q: eight k-steps, four per lane half
+                            const float4 av = *reinterpret_cast<const float4 *>(&As[cur][32 * wave + lrow][8 * q + 4 * lk]);
+                            const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[cur][lrow][8 * q + 4 * lk]);
+                            const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[cur][32 + lrow][8 * q + 4 * lk]);
+                            const float4 b2 = *reinterpret_cast<const float4 *>(&Bs[cur][64 + lrow][8 * q + 4 * lk]);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2.z, acc[2], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b2.w, acc[2], 0, 0, 0);
+                        };
+#pragma unroll
+                        for (int q = 0; q < BK / 16; ++q) product(q);
+                        if (kt + 1 < nkt) {
+                            store_tiles(cur ^ 1, ring[(d + 1) % kDepth]);
+                            load_tiles(min(kt + 1 + kDepth, nkt - 1) * BK, ring[(d + 1) % kDepth]);
+                        }
+#pragma unroll
+                        for (int q = BK / 16; q < BK / 8; ++q) product(q);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+
+        PSTAMP(3);
+        // gates and the new state of this tile; the state goes to LDS first so that it can leave as whole
+        // 128-byte lines (one 16-byte store per lane)
+        float rgv[16], zgv[16], ngv[16], ghv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool active = ((valid >> r) & 1) && t < lenv[r];
+            const float ghn = acc[2][r] + b_n;
+            const float rg = fast_sigmoid(gir[r] + acc[0][r] + b_r);
+            const float zg = fast_sigmoid(giz[r] + acc[1][r] + b_z);
+            const float ng = fast_tanh(gin[r] + rg * ghn);
+            const float hnew = (1.f - zg) * ng + zg * hp[r];
+            const float yv = active ? hnew : 0.f;
+            rgv[r] = rg; zgv[r] = zg; ngv[r] = ng; ghv[r] = ghn;
+            hp[r] = yv;
+            Hs[32 * wave + d_row(r, lk)][lrow] = yv;
+        }
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(s.ybuf + (long)t * B * H, step_bytes);
+#pragma unroll
+            for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
+                const int slot = tid + p * 256, row = slot >> 3, c4 = (slot & 7) << 2;
+                const float4 v = *reinterpret_cast<const float4 *>(&Hs[row][c4]);
+                // rows past the batch: an offset beyond the buffer, the store is dropped
+                const int off = m0 + row < B ? ((m0 + row) * H + u0 + c4) * 4 : 0x7fffffff;
+                st4_sc1(rs_y, off, v);
+            }
+        }
+        PSTAMP(4);
+        if (t + 1 < T) arrive(cnt);      // (also keeps Hs from being rewritten before every wave has read it)
+        else __syncthreads();
+        PSTAMP(5);
+        // what no workgroup waits for: the caller's y (when it is not the exchange buffer), the saved
+        // gates and h_n.  These stores drain while the next step's products run.
+        if (a.y_ext && a.y_ext != s.ybuf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + d_row(r, lk);
+                const long er = ((valid >> r) & 1) ? map_tb(a.ymap, t, m) : -1L;
+                if (er >= 0) a.y_ext[er * H + u] = hp[r];
+            }
+        }
+        {   // (absent tensors have empty descriptors; an offset beyond the block drops a lane's store)
+            float *gt = a.gates ? a.gates + (long)t * B * H : nullptr;
+            const __amdgpu_buffer_rsrc_t rs_r = rsrc_opt(gt, step_bytes), rs_z = rsrc_opt(gt ? gt + plane : nullptr, step_bytes),
+                                         rs_n = rsrc_opt(gt ? gt + 2 * plane : nullptr, step_bytes),
+                                         rs_h = rsrc_opt(gt ? gt + 3 * plane : nullptr, step_bytes),
+                                         rs_hn = rsrc_opt(a.h_n, step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = (valid >> r) & 1;
+                const int og = ok && t < lenv[r] ? roff[r] : 0x7fffffff;
+                st1(rs_r, og, 0, rgv[r]); st1(rs_z, og, 0, zgv[r]); st1(rs_n, og, 0, ngv[r]); st1(rs_h, og, 0, ghv[r]);
+                st1(rs_hn, ok && t == lenv[r] - 1 ? roff[r] : 0x7fffffff, 0, hp[r]);
+            }
+        }
+        PSTAMP(6);
+    }
+    PSTAMP_FLUSH(0)
+}
+
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwd s) {
     constexpr int BK = 32, LDA = kRows + 4, LDB = kUnits + 4;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
@@ -371,6 +698,217 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwd s) {
     }
 }
 
+struct PersistBwd {
+    BwdArgs b;
+    unsigned *sync;       // sync[0]: error word; sync[1 + mt]: arrivals of row tile mt; all zero at launch
+    int mt0, MT, mtx;
+};
+
+// Backward twin of gru_persist_fwd_kernel.  The workgroups of a row tile hand each other the gate gradients
+// of step t+1 (rows of `dg`: every 128-byte line is written whole, write-through, by one store instruction);
+// the carry d*z of the workgroup's own tile and the running bias sums stay in registers for all steps.
+template <int BK>
+__global__ __launch_bounds__(256) void gru_persist_bwd_kernel(PersistBwd s) {
+    // A tiles as in the forward kernel: rows k-contiguous, 16-byte writes and 16-byte fragment reads, MFMA
+    // step j of chunk q standing for k = 8q + 4*(lane >> 5) + j; the W_hh tile is k-major as in memory
+    constexpr int LDK = BK + 4, LDB = kUnits + 4, LDH = kUnits + 4;
+    // one LDS array: the operand tiles of the products, and -- once the products of a step are done -- the
+    // four gate-gradient tiles on their way out
+    constexpr int kTileFloats = 2 * kRows * LDK + 2 * BK * LDB, kOutFloats = 4 * kRows * LDH;
+    __shared__ __attribute__((aligned(16))) float lds[kTileFloats > kOutFloats ? kTileFloats : kOutFloats];
+    float (*As)[kRows][LDK] = reinterpret_cast<float (*)[kRows][LDK]>(lds);
+    float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * kRows * LDK);
+    float (*Gs)[kRows][LDH] = reinterpret_cast<float (*)[kRows][LDH]>(lds);
+    __shared__ int Ls[kRows];      // length of each sequence of the row tile (0 for rows past the batch)
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const BwdArgs &a = s.b;
+    const int H = a.H, B = a.B, T = a.T, NT = H / kUnits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int m0 = mt * kRows, u0 = nt * kUnits;
+    const int u = u0 + lrow;
+    unsigned *cnt = s.sync + 1 + mt;
+    const long plane = (long)T * B * H;
+    const long step_bytes = (long)B * 4 * H * 4;      // one step's rows of dg
+
+    if (tid < kRows) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+    __syncthreads();
+    // byte offset of (sequence of register r, unit u) inside one step's (B, H) block, rows past the batch
+    // clamped to the last one; every per-step operand is addressed as descriptor(step) + this offset
+    int roff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wave + d_row(r, lk), B - 1) * H + u) * 4;
+    const long bh_bytes = (long)B * H * 4;
+    // the caller's dy: time-major (row t*B + b) or batch-major (row b*T + t); s.dy_rows = rows of a sequence
+    const int dy_bt = a.dymap.mode == 1;
+    float cin[16];          // d_{t+1} * z_{t+1} of this workgroup's own tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+    float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f;   // column sums over this wave's 32 sequences, all steps
+
+    constexpr int KQ = BK / 4, PA = kRows * KQ / 256, PB = BK * 8 / 256;   // float4 slots: A kRows x BK/4, B BK x 8
+    static_assert(BK * 8 % 256 == 0, "whole W_hh slots per thread");
+    int a_off[PA];   // rows past the batch are clamped (their results are never stored): no conditional loads
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+        a_off[p] = (min(m0 + row, B - 1) * 4 * H + kc) * 4;
+    }
+    const int b_k = tid >> 3, b_c = (tid & 7) << 2;      // slot p of this thread: k = b_k + 32 p
+    const float *b_src = a.w_hh + (long)b_k * H + u0 + b_c;
+    struct Regs { float4 a[PA], b[PB]; };
+    const int nkt = 3 * H / BK;
+    const int t_last = a.dh0 ? -1 : 0;
+    PSTAMP_DECL
+
+    for (int t = T - 1; t >= t_last; --t) {
+        PSTAMP(7);
+        // operands of the epilogue (gate gradients of step t), requested before the wait and the products
+        const int tc = max(t, 0);
+        // No load below is conditional: absent tensors have empty descriptors (their loads give 0), and
+        // which tensor a descriptor points at is decided once per step, not per element.
+        float gr[16], gz[16], gn[16], ghn[16], hp[16], dy[16];
+        {
+            const float *gt = a.gates + (long)tc * B * H;
+            const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
+                                         rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_di = rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
+            // batch-major dy: the block of step tc starts tc rows in and its sequences are T rows apart
+            const __amdgpu_buffer_rsrc_t rs_de =
+                rsrc_opt(a.dy_ext ? a.dy_ext + (dy_bt ? (long)tc * H : (long)tc * B * H) : nullptr,
+                         dy_bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_dn = rsrc_opt(a.dh_n, bh_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                gr[r] = ld1(rs_r, roff[r], 0); gz[r] = ld1(rs_z, roff[r], 0);
+                gn[r] = ld1(rs_n, roff[r], 0); ghn[r] = ld1(rs_h, roff[r], 0);
+                hp[r] = ld1(rs_hp, roff[r], 0);
+                const int oe = dy_bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r];
+                const float e = ld1(rs_dn, roff[r], 0);
+                dy[r] = ld1(rs_di, roff[r], 0) + ld1(rs_de, oe, 0) + (tc == Ls[32 * wave + d_row(r, lk)] - 1 ? e : 0.f);
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+        PSTAMP(0);
+        if (t < T - 1) {
+            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
+            PSTAMP(1);
+            // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows; B = W_hh (3H,H)
+            const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
+            auto load_tiles = [&](int k0, Regs &g) {
+                const int kcol = k0 < 2 * H ? k0 : k0 + H;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) g.a[p] = ld4_sc1(rs_dg, a_off[p] + kcol * 4);
+#pragma unroll
+                for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(b_src + (long)(k0 + 32 * p) * H);
+            };
+            auto store_tiles = [&](int buf, const Regs &g) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+                    *reinterpret_cast<float4 *>(&As[buf][row][kc]) = g.a[p];
+                }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) *reinterpret_cast<float4 *>(&Bs[buf][b_k + 32 * p][b_c]) = g.b[p];
+            };
+            constexpr int kDepth = kPersistDepth;
+            Regs ring[kDepth];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) load_tiles(min(d, nkt - 1) * BK, ring[d]);
+            store_tiles(0, ring[0]);
+            load_tiles(min(kDepth, nkt - 1) * BK, ring[0]);
+            __syncthreads();
+            PSTAMP(2);
+            for (int kt0 = 0; kt0 < nkt; kt0 += kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int kt = kt0 + d, cur = kt & 1;
+                    if (kt < nkt) {
+                        auto product = [&](int q) {      // chunk q: eight k-steps, four per lane half
+                            const int k = 8 * q + 4 * lk;
+                            const float4 av = *reinterpret_cast<const float4 *>(&As[cur][32 * wave + lrow][k]);
+                            const float b0 = Bs[cur][k][lrow], b1 = Bs[cur][k + 1][lrow];
+                            const float b2 = Bs[cur][k + 2][lrow], b3 = Bs[cur][k + 3][lrow];
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[1], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc[1], 0, 0, 0);
+                        };
+#pragma unroll
+                        for (int q = 0; q < BK / 16; ++q) product(q);
+                        if (kt + 1 < nkt) {
+                            store_tiles(cur ^ 1, ring[(d + 1) % kDepth]);
+                            load_tiles(min(kt + 1 + kDepth, nkt - 1) * BK, ring[(d + 1) % kDepth]);
+                        }
+#pragma unroll
+                        for (int q = BK / 16; q < BK / 8; ++q) product(q);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+
+        PSTAMP(3);
+        if (t < 0) {   // gradient of the initial state
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + d_row(r, lk);
+                if (m < B) a.dh0[(long)m * H + u] = cin[r] + acc[0][r] + acc[1][r];
+            }
+            break;
+        }
+
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + d_row(r, lk);
+            const bool active = t < Ls[row];
+            const float dhc = cin[r] + acc[0][r] + acc[1][r];
+            const float d = active ? dy[r] + dhc : 0.f;
+            const float dn = d * (1.f - gz[r]);
+            const float dzz = d * (hp[r] - gn[r]);
+            const float an = active ? dn * (1.f - gn[r] * gn[r]) : 0.f;
+            const float dar = active ? an * ghn[r] * gr[r] * (1.f - gr[r]) : 0.f;
+            const float daz = active ? dzz * gz[r] * (1.f - gz[r]) : 0.f;
+            const float dgn = active ? an * gr[r] : 0.f;
+            cin[r] = active ? d * gz[r] : dhc;
+            Gs[0][row][lrow] = dar; Gs[1][row][lrow] = daz; Gs[2][row][lrow] = an; Gs[3][row][lrow] = dgn;
+            sr += dar; sz += daz; sn += an; sg += dgn;      // (zero for ended sequences and rows past the batch)
+        }
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(a.dg + (long)t * B * 4 * H, step_bytes);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
+                    const int slot = tid + p * 256, row = slot >> 3, c4 = (slot & 7) << 2;
+                    const float4 v = *reinterpret_cast<const float4 *>(&Gs[q][row][c4]);
+                    const int off = m0 + row < B ? ((m0 + row) * 4 * H + q * H + u0 + c4) * 4 : 0x7fffffff;
+                    st4_sc1(rs_o, off, v);
+                }
+        }
+        PSTAMP(4);
+        if (t > t_last) arrive(cnt);     // (also keeps Gs from being rewritten before every wave has read it)
+        PSTAMP(5);
+    }
+    PSTAMP_FLUSH(8)
+
+    sr += __shfl_xor(sr, 32); sz += __shfl_xor(sz, 32); sn += __shfl_xor(sn, 32); sg += __shfl_xor(sg, 32);
+    if (lk == 0) {
+        // one partial row per (row tile, wave); this workgroup is the only writer of its 32 columns
+        float *p = a.db_part + (long)(mt * 4 + wave) * 4 * H + u;
+        p[0] = sr; p[H] = sz; p[2 * H] = sn; p[3 * H] = sg;
+    }
+}
+
 }  // namespace
 
 // (32-bit element offsets inside one step's rows: B * 4H must stay below 2^31)
@@ -379,10 +917,51 @@ bool gru_step_supported(int B, int H) {
 }
 int gru_step_bias_rows(int B) { return 4 * ((B + kRows - 1) / kRows); }
 
-hipError_t launch_gru_step_fwd(const FwdArgs &a, hipStream_t s) {
+// Compute units of the current device (looked up once per process; the kernels are gfx950-only and a
+// process drives GPUs of one kind).  The persistent kernels need every workgroup of a launch resident.
+static int cu_count() {
+    static std::atomic<int> n{0};
+    int v = n.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = -1;
+        n.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+size_t gru_step_sync_words(int B) { return 1 + (size_t)((B + kRows - 1) / kRows); }
+
+// (the persistent kernels address one step's rows through 32-bit buffer offsets: the largest block, a step's
+// rows of dg, must stay below 2 GiB)
+static bool persist_ok(int B, int H, const unsigned *sync) {
+    return sync && !switches().no_persist && cu_count() >= H / kUnits && (long)B * 4 * H * 4 < (1L << 31);
+}
+
+hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s) {
     // the state of step t-1 is read back from the time-major output of this layer
-    const float *ysrc = a.y_int ? a.y_int : (a.ymap.mode == 0 ? a.y_ext : nullptr);
+    float *ysrc = a.y_int ? a.y_int : (a.ymap.mode == 0 ? a.y_ext : nullptr);
     if (!gru_step_supported(a.B, a.H) || !ysrc) return hipErrorInvalidValue;
+    if (persist_ok(a.B, a.H, sync)) {
+        const int NT = a.H / kUnits, MT = (a.B + kRows - 1) / kRows;
+        const int per_launch = cu_count() / NT;       // row tiles whose workgroups are resident together
+        hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+        for (int mt0 = 0; mt0 < MT; mt0 += per_launch) {
+            PersistFwd k;
+            k.f = a;
+            k.ybuf = ysrc;
+            k.sync = sync;
+            k.mt0 = mt0;
+            k.MT = min(per_launch, MT - mt0);
+            k.mtx = (k.MT + 7) / 8;
+            if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
+            else TGRU_LAUNCH(gru_persist_fwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
+        }
+        return hipGetLastError();
+    }
     StepFwd k;
     k.f = a;
     k.MT = (a.B + kRows - 1) / kRows;
@@ -398,6 +977,29 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, hipStream_t s) {
 
 hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
     if (!gru_step_supported(a.B, a.H) || !carry || !a.y_int) return hipErrorInvalidValue;
+    // the persistent kernel keeps the carry in registers: the carry buffer (B x H floats) holds its sync words
+    unsigned *sync = reinterpret_cast<unsigned *>(carry);
+    // the caller's dy is read through one descriptor per step: time-major or batch-major rows only, and a
+    // batch-major tensor must stay below 2 GiB
+    const bool dy_ok = !a.dy_ext || a.dymap.mode == 0 ||
+                       (a.dymap.mode == 1 && (long)a.B * a.T * a.H * 4 < (1L << 31));
+    if ((size_t)a.B * a.H >= gru_step_sync_words(a.B) && dy_ok && persist_ok(a.B, a.H, sync)) {
+        const int NT = a.H / kUnits, MT = (a.B + kRows - 1) / kRows;
+        const int per_launch = cu_count() / NT;
+        hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+        for (int mt0 = 0; mt0 < MT; mt0 += per_launch) {
+            PersistBwd k;
+            k.b = a;
+            k.sync = sync;
+            k.mt0 = mt0;
+            k.MT = min(per_launch, MT - mt0);
+            k.mtx = (k.MT + 7) / 8;
+            if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_bwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
+            else TGRU_LAUNCH(gru_persist_bwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
+        }
+        return hipGetLastError();
+    }
     StepBwd k;
     k.b = a;
     k.carry = carry;

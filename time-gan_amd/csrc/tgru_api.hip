@@ -18,6 +18,7 @@ void Switches::read() {
     no_vec = on("TGRU_NO_VEC");
     no_mid = on("TGRU_NO_MID");
     no_step = on("TGRU_NO_STEP");
+    no_persist = on("TGRU_NO_PERSIST");
     no_h24 = on("TGRU_NO_H24");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
 }
@@ -56,6 +57,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_VEC=1         MFMA whole-stack kernels instead of one sequence per workgroup (gru_vec.hip)
 //   TGRU_NO_MID=1         16-sequence kernels of gru_recurrent.hip instead of gru_mid.hip (32 < H <= 128)
 //   TGRU_NO_STEP=1        persistent 16-sequence kernels instead of one launch per step (gru_step.hip)
+//   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
 //   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
 bool use_small(int In, int H, int L) {
@@ -385,7 +387,8 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
         f.lengths = lengths;
         f.B = B; f.T = T; f.H = H;
-        if (stepk) TGRU_HIP(launch_gru_step_fwd(f, s));
+        // (the packed-W_hh region of the workspace is free on this path: it holds the sync words)
+        if (stepk) TGRU_HIP(launch_gru_step_fwd(f, reinterpret_cast<unsigned *>(wp), s));
         else if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
         else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;

@@ -18,7 +18,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_h24, gemm_guarded;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, gemm_guarded;
     void read();
     Switches() { read(); }
 };
@@ -216,7 +216,11 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
 // backward needs a (B,H) carry buffer and leaves gru_step_bias_rows(B) rows in a.db_part.
 bool gru_step_supported(int B, int H);
 int gru_step_bias_rows(int B);
-hipError_t launch_gru_step_fwd(const FwdArgs &a, hipStream_t s);
+// `sync`: gru_step_sync_words(B) 32-bit words of device memory for the persistent variants (time loop inside
+// the kernel, the workgroups of a row tile wait for each other through counters); null, or TGRU_NO_PERSIST=1,
+// selects one launch per step.
+size_t gru_step_sync_words(int B);
+hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s);
 hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s);
 
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
