@@ -20,10 +20,18 @@ constexpr int NTHREADS = 256;
 // A per-lane condition in front of a load costs a branch and serialises the loads of a tile.
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool FAST>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
+    // LDS tiles keep the orientation the operand has in memory, so a tile is always filled with one
+    // 16-byte write per 16-byte load: a k-contiguous operand as [row][k] (rows of BK floats + 4 of padding),
+    // the other kind as [k][row].  The reduction index of an MFMA step may be permuted freely as long as
+    // both operands agree: step j of chunk q stands for k = 8q + 4*(lane >> 5) + j.  A k-contiguous
+    // operand then supplies FOUR steps with one 16-byte fragment read (conflict-free: 80-byte rows).
+    constexpr int LDK = BK + 4;
     constexpr int LDA_S = BM + 4;
     constexpr int LDB_S = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB_S];
+    constexpr int A_FLOATS = A_KC ? BM * LDK : BK * LDA_S;
+    constexpr int B_FLOATS = B_KC ? BN * LDK : BK * LDB_S;
+    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad wave tiling");
@@ -197,27 +205,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             if (tid + p * NTHREADS < SLOTS_A) {
-                if (A_KC) {
-                    As[buf][a_c[p] + 0][a_r[p]] = ra[p].x;
-                    As[buf][a_c[p] + 1][a_r[p]] = ra[p].y;
-                    As[buf][a_c[p] + 2][a_r[p]] = ra[p].z;
-                    As[buf][a_c[p] + 3][a_r[p]] = ra[p].w;
-                } else {
-                    *reinterpret_cast<float4 *>(&As[buf][a_r[p]][a_c[p]]) = ra[p];
-                }
+                if (A_KC) *reinterpret_cast<float4 *>(&As[buf][a_r[p] * LDK + a_c[p]]) = ra[p];
+                else *reinterpret_cast<float4 *>(&As[buf][a_r[p] * LDA_S + a_c[p]]) = ra[p];
             }
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             if (tid + p * NTHREADS < SLOTS_B) {
-                if (B_KC) {
-                    Bs[buf][b_c[p] + 0][b_r[p]] = rb[p].x;
-                    Bs[buf][b_c[p] + 1][b_r[p]] = rb[p].y;
-                    Bs[buf][b_c[p] + 2][b_r[p]] = rb[p].z;
-                    Bs[buf][b_c[p] + 3][b_r[p]] = rb[p].w;
-                } else {
-                    *reinterpret_cast<float4 *>(&Bs[buf][b_r[p]][b_c[p]]) = rb[p];
-                }
+                if (B_KC) *reinterpret_cast<float4 *>(&Bs[buf][b_r[p] * LDK + b_c[p]]) = rb[p];
+                else *reinterpret_cast<float4 *>(&Bs[buf][b_r[p] * LDB_S + b_c[p]]) = rb[p];
             }
         }
     };
@@ -244,17 +240,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
             if (FAST) load_fast(kbeg + (kt + 1) * BK); else load_guarded(kbeg + (kt + 1) * BK);
         }
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int q = 0; q < BK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
+            const int k = 8 * q + 4 * lk;
+            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][kk + lk][wm * WTM + i * 32 + lrow];
+            for (int i = 0; i < TM; ++i) {
+                const int m = wm * WTM + i * 32 + lrow;
+                if (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&As[cur][m * LDK + k]);
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kk + lk][wn * WTN + j * 32 + lrow];
+                    for (int e = 0; e < 4; ++e) a[i][e] = As[cur][(k + e) * LDA_S + m];
+                }
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * WTN + j * 32 + lrow;
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&Bs[cur][n * LDK + k]);
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[cur][(k + e) * LDB_S + n];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) store_tiles(cur ^ 1);
         __syncthreads();
