@@ -1,26 +1,47 @@
-// Weight gradients of one layer for mid-size hidden states (32 < H <= 128), both matrices in one pass:
+// Weight gradients of one layer for mid-size hidden states (32 < H <= 128), both matrices in one launch:
 //      dW_ih (3H x In) = dgi^T . X          dW_hh (3H x H) = dgh^T . H_prev
 // contracted over all K = T*B rows.  dgi = dg[:, 0:3H], dgh = dg[:, 0:2H] | dg[:, 3H:4H].
 //
-// A workgroup owns a contiguous range of rows and ALL output tiles: wave ti holds the 32-row block
-// ti of the 3H output rows against every 32-column block of [X | H_prev] (up to eight 32x32
-// accumulators).  Rows are streamed through LDS in stages of 16 with direct-to-LDS loads, double
-// buffered; every input byte is fetched once per workgroup (a tiled split-K GEMM re-reads dg once
-// per column tile and X once per row tile).  Each workgroup leaves one partial [dW_ih | dW_hh];
-// a second kernel sums the partials in a fixed order.
+// The rows are cut into chunks and every chunk into SIX jobs, one workgroup each: (gate g, matrix m) computes
+// rows [gH, (g+1)H) of dW_ih (m = 0) or dW_hh (m = 1).  A job reads ONE H-wide plane of dg (da_r, da_z, and
+// da_n for dW_ih / da_n*r for dW_hh) and the chunk's rows of X or H_prev, streamed through LDS in stages of
+// 32 rows with direct-to-LDS loads into a ring of three slots (two stages in flight while one is read, one
+// barrier per stage); wave (i, q) holds the 32 x 32 output tile (row block i of the gate, column block q) and
+// reads the next stage's fragments into registers while the matrix pipe works on the current ones.  Each chunk leaves one partial [dW_ih | dW_hh]; a second kernel sums the
+// partials in a fixed order.  (One workgroup per chunk computing all of both matrices left 256 partials of
+// 3H x (In + H) floats: at H = 96 more bytes written and re-read than the inputs hold.)
 #include "tgru_internal.h"
 
 namespace tgru {
 namespace midw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kRows = 16;          // rows per stage
-constexpr int kMaxNT = 6;          // 32-column blocks of [X | H_prev]: In + H <= 192
+constexpr int kRows = 32;          // rows per stage
+constexpr int kJobs = 6;           // (gate, matrix) jobs per chunk of rows
+constexpr int kSlots = 3;          // LDS ring: the stage being read and two in flight
+constexpr int kMaxLoads = 8;       // 64-lane load instructions one wave issues per stage, at most (H = In = 32)
 constexpr int kOOB = 0x7ffffff0;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
-__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// all but this wave's n youngest loads (one stage's worth) have landed
+__device__ __forceinline__ void wait_all_but(int n) {
+    switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    default: wait_vmcnt<8>(); break;
+    }
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
 }
@@ -38,116 +59,177 @@ struct MidWgradArgs {
     const float *y;                // (K, H) this layer's output, time-major: H_prev row k = y row k - B
     const float *h0;               // (B, H) or null: H_prev rows k < B
     float *slabs; long slab_stride;
-    int rows_per_wg;               // multiple of kRows
+    int rows_per_chunk;            // multiple of kRows
+    int njobs;                     // workgroups with work: 6 per chunk that owns rows
     int B, T, H;
 };
 
+// HC: H = In = HC known at compile time (LDS offsets become immediates, the edge masks fold away), 0: any shape
+template <int HC>
 __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
     using namespace midw;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x ( dgs[16][4H] | xs[16][In] | hs[16][H] )
-    const int H = a.H, In = a.In, B = a.B;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // kSlots x ( as[kRows][H] | bs[kRows][W] )
+    const int H = HC ? HC : a.H, In = HC ? HC : a.In, B = a.B;
     const int K = a.T * B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;                 // = ceil(3H / 32) row blocks
-    const int ntx = (In + 31) / 32, nth = (H + 31) / 32;
-    const int stage_floats = kRows * (4 * H + In + H);
-    const int kbeg = blockIdx.x * a.rows_per_wg, kend = min(K, kbeg + a.rows_per_wg);
+    const int nwaves = blockDim.x >> 6;
+    // Workgroup ids go round-robin over the 8 XCDs; the six jobs of a chunk read the same rows, so they are
+    // given ids that land on one XCD (one L2): XCD x owns jobs [x * per_xcd, (x + 1) * per_xcd)
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= a.njobs) return;
+    const int chunk = lin / kJobs, job = lin - chunk * kJobs;
+    const int gate = job >> 1, hh = job & 1;           // which H rows of which matrix
+    const int W = hh ? H : In;                          // width of the B operand (X or H_prev rows)
+    const int acol = hh && gate == 2 ? 3 * H : gate * H;   // first column of this job's plane of dg
+    const int nq = (W + 31) / 32;                       // column blocks; waves are (row block, column block)
+    const int stage_floats = kRows * (H + W);
+    const int kbeg = chunk * a.rows_per_chunk, kend = min(K, kbeg + a.rows_per_chunk);
     const __amdgpu_buffer_rsrc_t rs_dg = make_rsrc(a.dg, (long)K * 4 * H * 4);
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.xin, (long)K * In * 4);
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y, (long)K * H * 4);
     const __amdgpu_buffer_rsrc_t rs_h0 = make_rsrc(a.h0, (long)B * H * 4);
 
-    // stage loader: 16-byte chunks of the stage, flattened dgs | xs | hs, dealt round-robin to the waves
-    const int cdg = kRows * H, cx = kRows * In / 4, ch = kRows * H / 4;   // chunks per part
-    const int ninstr = (cdg + cx + ch + 63) / 64;
+    // A stage = 16-byte chunks flattened as | bs, dealt round-robin to the waves as 64-lane instructions; an
+    // instruction never straddles the two parts (H and In are multiples of 16: both parts are whole
+    // instructions).  Every wave issues the same number of loads for every stage -- rows past the chunk's end
+    // are loaded out of range (zeros), and a wave whose share is one short loads out of range into a spare
+    // kilobyte behind the ring -- so "all but my youngest n loads" is "all but the youngest stage".
+    const int ca = kRows * H / 4, cb = kRows * W / 4;
+    const int ninstr = (ca + cb) / 64;
+    const int per_wave = HC ? kRows * 2 * HC / 256 / ((HC / 32) * (HC / 32)) + 1 : (ninstr + nwaves - 1) / nwaves;
+    constexpr int kLoads = HC ? kRows * 2 * HC / 256 / ((HC / 32) * (HC / 32)) + 1 : kMaxLoads;
+    float *const spare = smem + kSlots * kRows * (H + (H > In ? H : In));
+    // per-lane byte offset of each load relative to the stage's first row, and the row it belongs to (the
+    // divisions are done once, not per stage)
+    int rel[kLoads], rrow[kLoads];
+    const int brow_bytes = (!hh && a.x_bt ? a.T : 1) * W * 4;           // distance between consecutive rows of B
+#pragma unroll
+    for (int j = 0; j < kLoads; ++j) {
+        const int i = wave + j * nwaves;
+        const int c = i * 64 + lane;
+        if (i >= ninstr) {
+            rrow[j] = 1 << 20; rel[j] = 0;                                 // never in range
+        } else if (c < ca) {
+            const int r = c / (H / 4), o = c - r * (H / 4);
+            rrow[j] = r; rel[j] = r * 4 * H * 4 + (acol + 4 * o) * 4;
+        } else {
+            const int cc = c - ca, r = cc / (W / 4), o = cc - r * (W / 4);
+            rrow[j] = r; rel[j] = r * brow_bytes + 16 * o;
+        }
+    }
     auto issue = [&](int k0, float *buf) {
-        const bool first_rows = k0 < B;            // B is a multiple of kRows: a stage is all-initial-state or none
-        for (int i = wave; i < ninstr; i += nwaves) {
-            const int c = i * 64 + lane;
-            if (c < cdg) {
-                const int r = c / H, o = c - r * H;                       // row, 16-byte column
-                lds_load_b128(rs_dg, buf + i * 256, (k0 + r < kend) ? ((k0 + r) * 4 * H + 4 * o) * 4 : kOOB);
-            } else if (c < cdg + cx) {
-                const int cc = c - cdg, r = cc / (In / 4), o = cc - r * (In / 4);
-                const int k = k0 + r;
-                int row = k;
-                if (a.x_bt) { const int t = k / B, b = k - t * B; row = b * a.T + t; }
-                lds_load_b128(rs_x, buf + i * 256, (k < kend) ? (row * In + 4 * o) * 4 : kOOB);
-            } else {
-                const int cc = c - cdg - cx, r = cc / (H / 4), o = cc - r * (H / 4);
-                const int k = k0 + r;
-                const bool ok = cc < ch && k < kend;
-                if (first_rows) lds_load_b128(rs_h0, buf + i * 256, ok ? (k * H + 4 * o) * 4 : kOOB);
-                else lds_load_b128(rs_y, buf + i * 256, ok ? ((k - B) * H + 4 * o) * 4 : kOOB);
-            }
+        // B is a multiple of kRows: the rows of a stage share their time step, and are all initial-state rows or none
+        const int base_a = k0 * 4 * H * 4;
+        int base_b;
+        __amdgpu_buffer_rsrc_t rs_b;
+        if (!hh) {
+            rs_b = rs_x;
+            if (a.x_bt) { const int t = k0 / B, b0 = k0 - t * B; base_b = (b0 * a.T + t) * In * 4; }
+            else base_b = k0 * In * 4;
+        } else if (k0 < B) { rs_b = rs_h0; base_b = k0 * H * 4; }
+        else { rs_b = rs_y; base_b = (k0 - B) * H * 4; }
+        const int left = kend - k0;                                      // rows of the stage that exist (may be <= 0)
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) {
+            if (!HC && j >= per_wave) break;
+            const int i = wave + j * nwaves;
+            float *dst = i < ninstr ? buf + i * 256 : spare;
+            if (i * 64 < ca) lds_load_b128(rs_dg, dst, rrow[j] < left ? base_a + rel[j] : kOOB);
+            else lds_load_b128(rs_b, dst, rrow[j] < left ? base_b + rel[j] : kOOB);
         }
     };
-    // NOTE: a 64-lane instruction must not straddle two parts (different descriptors): the parts are
-    // padded to whole instructions by the host-side choice of sizes (H, In multiples of 16)
 
-    // ---- this wave's output rows and its lane constants --------------------------------------------
+    // ---- this wave's output tile ----------------------------------------------------------------------
     const int i32 = lane & 31, kk = lane >> 5;
-    const int m = wave * 32 + i32;                       // output row (gate-major, 0..3H)
-    const bool mrow = m < 3 * H;
-    const int acol_x = mrow ? m : 0;
-    const int acol_h = mrow ? (m < 2 * H ? m : m + H) : 0;
-    const float amask = mrow ? 1.f : 0.f;
-    f32x16 acc[kMaxNT];
-    // per column block q of [X | H_prev]: where its element of a stage row lives, and which A operand it pairs with
-    int boff[kMaxNT], bstr[kMaxNT];
-    float bmask[kMaxNT];
-    bool useh[kMaxNT];
+    const int wi = wave / nq, wq = wave - wi * nq;       // row block of the gate, column block
+    const int m = wi * 32 + i32;                         // output row inside the gate's H rows
+    const int n = wq * 32 + i32;                         // output column
+    // Lanes of a tile's rows >= H or columns >= W read some valid element instead: row m of the A operand only
+    // reaches row m of the product (column n of B only column n), and those are never stored.
+    const int aoff = m < H ? m : 0, boff = kRows * H + (n < W ? n : 0);
+    f32x16 acc, acc9;
 #pragma unroll
-    for (int q = 0; q < kMaxNT; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-        const bool isx = q < ntx;
-        const int c = (isx ? q : q - ntx) * 32 + i32;
-        const int width = isx ? In : H;
-        const bool ok = q < ntx + nth && c < width;
-        useh[q] = !isx;
-        bstr[q] = width;
-        boff[q] = (isx ? kRows * 4 * H : kRows * (4 * H + In)) + (ok ? c : 0);
-        bmask[q] = ok ? 1.f : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = acc9[r] = 0.f;
+    // H = In = 96 has nine tiles: eight waves (two per SIMD: nine would leave one SIMD with half again the
+    // others' products) own one each and share the ninth, each taking two of a stage's sixteen row pairs of it.
+    constexpr bool kShared = HC == 96;
+    constexpr int kFrag = kRows / 2 + (kShared ? 2 : 0);
 
-    int cur = 0;
-    if (kbeg < kend) issue(kbeg, smem);
-    for (int k0 = kbeg; k0 < kend; k0 += kRows) {
-        wait_vm0();
-        lds_barrier();                                   // stage `cur` has landed for every wave
-        if (k0 + kRows < kend) issue(k0 + kRows, smem + (cur ^ 1) * stage_floats);
-        const float *st = smem + cur * stage_floats;
+    // Stage s lives in ring slot s % 3.  The fragments of stage s + 1 are read from LDS into registers while
+    // the matrix pipe works on the fragments of stage s read one turn earlier: a wave's LDS reads and address
+    // arithmetic hide behind its own products instead of alternating with them between barriers.
+    const int nstages = (kend - kbeg + kRows - 1) / kRows;
+    float fa0[kFrag], fb0[kFrag], fa1[kFrag], fb1[kFrag];
+    const int r9 = (4 * wave + kk) * H + 64 + i32;       // shared tile: rows 64.., columns 64.., row pairs 2*wave, 2*wave + 1
+    auto read_frags = [&](int slot, float (&av)[kFrag], float (&bv)[kFrag]) {
+        const float *st = smem + slot * stage_floats;
 #pragma unroll
         for (int s2 = 0; s2 < kRows / 2; ++s2) {
             const int r = 2 * s2 + kk;
-            const float ax = st[r * 4 * H + acol_x] * amask;
-            const float ah = st[r * 4 * H + acol_h] * amask;
+            av[s2] = st[r * H + aoff];
+            bv[s2] = st[boff + r * W];
+        }
+        if constexpr (kShared) {
 #pragma unroll
-            for (int q = 0; q < kMaxNT; ++q) {
-                const float b = st[boff[q] + r * bstr[q]] * bmask[q];
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(useh[q] ? ah : ax, b, acc[q], 0, 0, 0);
+            for (int e = 0; e < 2; ++e) {
+                av[kRows / 2 + e] = st[r9 + 2 * e * HC];
+                bv[kRows / 2 + e] = st[kRows * HC + r9 + 2 * e * HC];
             }
         }
-        lds_barrier();                                   // everyone is done reading stage `cur`
-        cur ^= 1;
+    };
+    int slot = 0;                                        // ring slot of the stage whose products are due
+    auto turn = [&](int sti, float (&av)[kFrag], float (&bv)[kFrag], float (&nav)[kFrag], float (&nbv)[kFrag]) {
+        if (HC) wait_vmcnt<kLoads>(); else wait_all_but(per_wave);      // my loads of stage sti + 1 have landed (sti + 2 may be in flight)
+        lds_barrier();                                   // so have everyone's, and everyone holds stage sti in registers
+        issue(kbeg + (sti + 3) * kRows, smem + slot * stage_floats);    // into the slot stage sti was in
+        slot = slot == kSlots - 1 ? 0 : slot + 1;
+        read_frags(slot, nav, nbv);
+        __builtin_amdgcn_sched_barrier(0);               // the reads are issued before the products, not sunk to their use
+#pragma unroll
+        for (int s2 = 0; s2 < kRows / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+        if constexpr (kShared) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                acc9 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kRows / 2 + e], bv[kRows / 2 + e], acc9, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(kbeg, smem);
+    issue(kbeg + kRows, smem + stage_floats);
+    if (HC) wait_vmcnt<kLoads>(); else wait_all_but(per_wave);
+    lds_barrier();                                       // stage 0 has landed
+    issue(kbeg + 2 * kRows, smem + 2 * stage_floats);
+    read_frags(0, fa0, fb0);
+    for (int sti = 0; sti < nstages; sti += 2) {
+        turn(sti, fa0, fb0, fa1, fb1);
+        if (sti + 1 < nstages) turn(sti + 1, fa1, fb1, fa0, fb0);
     }
+    wait_vmcnt<0>();                                     // the loads past the end still target this workgroup's LDS
     mfma_drain();
 
-    // ---- partial [dW_ih | dW_hh] of this workgroup: register r of lane (hh, j) is row 8*(r/4)+r%4+4*hh
-    float *slab = a.slabs + (long)blockIdx.x * a.slab_stride;
+    // ---- this job's rows of the chunk's partial [dW_ih | dW_hh]: register r of lane (kk, j) is row
+    // 8*(r/4) + r%4 + 4*kk of the tile
+    float *dst = a.slabs + (long)chunk * a.slab_stride + (hh ? (long)3 * H * In : 0) + (long)gate * H * W;
 #pragma unroll
-    for (int q = 0; q < kMaxNT; ++q) {
-        if (q >= ntx + nth) break;
-        const bool isx = q < ntx;
-        const int N = isx ? In : H;
-        const int c = (isx ? q : q - ntx) * 32 + i32;
-        float *dst = slab + (isx ? 0 : (long)3 * H * In);
+    for (int r = 0; r < 16; ++r) {
+        const int row = wi * 32 + 8 * (r / 4) + (r % 4) + 4 * kk;
+        if (row < H && n < W) dst[(long)row * W + n] = acc[r];
+    }
+    if constexpr (kShared) {
+        // the eight partial sums of the shared tile, added in wave order
+        lds_barrier();                                   // every wave is past its last fragment read: the ring is free
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + 8 * (r / 4) + (r % 4) + 4 * kk;
-            if (row < 3 * H && c < N) dst[(long)row * N + c] = acc[q][r];
+        for (int r = 0; r < 16; ++r) smem[(wave * 16 + r) * 64 + lane] = acc9[r];
+        lds_barrier();
+        for (int e = threadIdx.x; e < 16 * 64; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += smem[w * 1024 + e];
+            const int r = e >> 6, l = e & 63;
+            const int row = 64 + 8 * (r / 4) + (r % 4) + 4 * (l >> 5), col = 64 + (l & 31);
+            dst[(long)row * HC + col] = v;
         }
     }
 }
@@ -186,13 +268,15 @@ __global__ __launch_bounds__(256) void mid_wgrad_reduce_kernel(const float *slab
 // (H and In multiples of 16), a stage must not mix initial-state rows with later ones (B multiple of
 // 16), byte offsets must fit 31 bits.
 bool gru_mid_wgrad_supported(int B, int T, int In, int H) {
-    if (!gru_mid_supported(H) || H > 96 || In > 96 || (H & 15) || (In & 15) || (B & 15)) return false;   // 9 waves x 6 accumulator tiles
+    if (!gru_mid_supported(H) || H > 96 || In > 96 || (H & 15) || (In & 15) || B % midw::kRows) return false;   // at most 3 x 3 waves
     const long widest = 4L * H > In ? 4L * H : In;
     return (long)T * B * widest * 4 < (1L << 31);
 }
+// chunks of rows (= partial results); six workgroups per chunk, about one workgroup per CU in all
 int gru_mid_wgrad_workgroups(int B, int T) {
     const int stages = (B * T + midw::kRows - 1) / midw::kRows;
-    return stages < 256 ? stages : 256;      // one workgroup per CU measured best (128: +12 %, 512: +8 %)
+    const int chunks = 256 / midw::kJobs;
+    return stages < chunks ? stages : chunks;
 }
 long gru_mid_wgrad_slab_floats(int In, int H) { return 3L * H * (In + H); }
 
@@ -203,18 +287,25 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
     a.dg = dg; a.xin = xin; a.In = In; a.x_bt = x_bt; a.y = y; a.h0 = h0; a.slabs = slabs;
     a.slab_stride = gru_mid_wgrad_slab_floats(In, H);
     a.B = B; a.T = T; a.H = H;
-    const int nwg = gru_mid_wgrad_workgroups(B, T);
+    const int nchunks = gru_mid_wgrad_workgroups(B, T);
     const int K = B * T;
-    a.rows_per_wg = ((K + nwg - 1) / nwg + midw::kRows - 1) / midw::kRows * midw::kRows;
-    const int nwaves = (3 * H + 31) / 32;
-    const size_t lds = (size_t)2 * midw::kRows * (4 * H + In + H) * sizeof(float);
+    a.rows_per_chunk = ((K + nchunks - 1) / nchunks + midw::kRows - 1) / midw::kRows * midw::kRows;
+    const int widest = In > H ? In : H;
+    const bool nine = H == 96 && In == 96;              // eight waves share the ninth tile
+    const int nwaves = nine ? 8 : ((H + 31) / 32) * ((widest + 31) / 32);
+    const size_t lds = (size_t)midw::kSlots * midw::kRows * (H + widest) * sizeof(float) + 1024;   // ring + spare
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gru_mid_wgrad_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gru_mid_wgrad_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(gru_mid_wgrad_kernel<96>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int used = (K + a.rows_per_wg - 1) / a.rows_per_wg;     // workgroups that own rows
-    TGRU_LAUNCH(gru_mid_wgrad_kernel, dim3(used), dim3(64 * nwaves), lds, s, a);
+    const int used = (K + a.rows_per_chunk - 1) / a.rows_per_chunk;     // chunks that own rows
+    a.njobs = used * midw::kJobs;
+    if (nine) TGRU_LAUNCH(gru_mid_wgrad_kernel<96>, dim3((a.njobs + 7) / 8 * 8), dim3(64 * nwaves), lds, s, a);
+    else TGRU_LAUNCH(gru_mid_wgrad_kernel<0>, dim3((a.njobs + 7) / 8 * 8), dim3(64 * nwaves), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long na = 3L * H * In, nb = 3L * H * H;
