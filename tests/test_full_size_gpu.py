@@ -89,10 +89,18 @@ def test_three_phase_steps_at_the_energy_dimensions():
 
     def check_params(tag, rtol, atol_abs):
         # Adam moves a parameter by about lr = 1e-3 per step whatever the gradient's size: a rounding-level
-        # difference in a near-zero gradient shows up as a fraction of lr, hence the absolute term
+        # difference in a near-zero gradient shows up as a fraction of lr, hence the absolute term.  A network's
+        # FIRST Adam step is exactly +-lr per element, so an element whose gradient is rounding noise around
+        # zero can land 2 lr from the reference: at most one element in 5000 may do that, none may exceed it.
+        lr = 1e-3
         for k in cpu.nets:
             for (name, pc), (_, pg) in zip(cpu.nets[k].state_dict().items(), gpu.nets[k].state_dict().items()):
-                assert_close(pg.cpu().numpy(), pc.numpy(), rtol, 0.0, f"{tag} {k}.{name}", atol_abs=atol_abs)
+                got, ref = pg.cpu().numpy().astype(np.float64), pc.numpy().astype(np.float64)
+                err = np.abs(got - ref)
+                bad = err > atol_abs + rtol * np.abs(ref)
+                assert bad.sum() <= max(1, bad.size // 5000) and float(err.max(initial=0.0)) <= 2.2 * lr + atol_abs, \
+                    (f"{tag} {k}.{name}: {int(bad.sum())}/{bad.size} elements out of tolerance, "
+                     f"max abs err {err.max():.3e}, max |ref| {np.abs(ref).max():.3e}")
 
     le_c, le_g = cpu.embedding_step(x), gpu.embedding_step(x.cuda())
     assert_close([le_g], [le_c], 1e-4, 0, "embedding loss")
