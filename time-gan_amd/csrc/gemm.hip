@@ -343,6 +343,7 @@ static hipError_t launch_cfg(const GemmArgs &g0, bool a_kc, bool b_kc, int nslab
 
 hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (!switches().no_rows && rows_gemm_supported(g, a_kc, b_kc, nslabs)) return launch_rows_gemm(g, b_kc, s);
     // narrow outputs get the 128x32 tile, everything else 128x128
     const int waste128 = ((g.N + 127) / 128) * 128 - g.N;
     const int waste32 = ((g.N + 31) / 32) * 32 - g.N;

@@ -20,6 +20,7 @@ void Switches::read() {
     no_step = on("TGRU_NO_STEP");
     no_persist = on("TGRU_NO_PERSIST");
     no_h24 = on("TGRU_NO_H24");
+    no_rows = on("TGRU_NO_ROWS");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
 }
 Switches &switches() {

@@ -18,7 +18,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, gemm_guarded;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, gemm_guarded;
     void read();
     Switches() { read(); }
 };
@@ -87,6 +87,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipStream_t s);
+// row-streaming kernel for the H = In = 96 input projection and its transpose (launch_gemm dispatches to it)
+bool rows_gemm_supported(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs);
+hipError_t launch_rows_gemm(const GemmArgs &g, bool b_kc, hipStream_t s);
 
 // out[i] (=|+=) sum_z slabs[z*stride + i], i < n
 hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float *out, long n,
