@@ -4,7 +4,7 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NACC>
-__global__ __launch_bounds__(256) void k(float *out, int n, float av, float bv) {
+__global__ __launch_bounds__(512) void k(float *out, int n, float av, float bv) {
     f32x4 acc[NACC];
     for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
     for (int it = 0; it < n; ++it) {
@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k(float *out, int n, float av, float bv) 
     }
     float s = 0.f;
     for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 template <int NACC> void run(float *out, int n, int waves) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -135,6 +135,47 @@ def test_mid_hidden_with_initial_state_and_ragged_lengths():
             assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
+@pytest.mark.parametrize("switches", ["default", "no_fuse", "no_fuse_no_rows"])
+@pytest.mark.parametrize("batch_first", [True, False])
+def test_energy_width_with_initial_state_and_ragged_lengths(switches, batch_first, monkeypatch):
+    """H = In = 96 has kernels of its own: the forward kernel that computes the input projection itself
+    (TGRU_NO_FUSE=1 switches it off) and the row-streaming products for gi and dX (TGRU_NO_ROWS=1 sends those
+    to the tile kernel).  All on the same case: 30 sequences (not a multiple of four: the last workgroup is
+    short), ragged lengths, an initial state, both input layouts."""
+    import timegan_amd as tg
+    for k in ("TGRU_NO_FUSE", "TGRU_NO_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    if switches != "default":
+        monkeypatch.setenv("TGRU_NO_FUSE", "1")
+    if switches == "no_fuse_no_rows":
+        monkeypatch.setenv("TGRU_NO_ROWS", "1")
+    tg.reload_switches()
+    B, T, H, L = 30, 7, 96, 2
+    lens = [7] * 9 + [6] * 5 + [4] * 8 + [2] * 5 + [1] * 3
+    torch.manual_seed(11)
+    ref = nn.GRU(H, H, L, batch_first=batch_first)
+    ours = tg.GRU(H, H, L, batch_first=batch_first).to("cuda:0")
+    ours.load_state_dict(ref.state_dict())
+    x = torch.rand(B, T, H) if batch_first else torch.rand(T, B, H)
+    h0 = torch.randn(L, B, H)
+    xr = x.clone().requires_grad_(True); hr0 = h0.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True); ho0 = h0.clone().cuda().requires_grad_(True)
+    pr = nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=batch_first, enforce_sorted=True)
+    yr, hnr = ref(pr, hr0)
+    yr, _ = nn.utils.rnn.pad_packed_sequence(yr, batch_first=batch_first, padding_value=0, total_length=T)
+    yo, hno = ours(xo, ho0, lengths=lens)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(1))
+    ((yr * gy).sum() + hnr.sum()).backward()
+    ((yo * gy.cuda()).sum() + hno.sum()).backward()
+    tag = f"H96 {switches} {'(B,T)' if batch_first else '(T,B)'}"
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " y")
+    assert_close(hno.detach().cpu().numpy(), hnr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, tag + " h_n")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dx")
+    assert_close(ho0.grad.cpu().numpy(), hr0.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " dh0")
+    for (name, p_), (_, q_) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
+
+
 @pytest.mark.parametrize("family", ["persistent_tiles", "launch_per_step", "sixteen_sequences"])
 def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch):
     """H > 128 in multiples of 32 runs on 128-sequence x 32-unit tiles with the time loop inside the kernel

@@ -21,6 +21,7 @@ void Switches::read() {
     no_persist = on("TGRU_NO_PERSIST");
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
+    no_fuse = on("TGRU_NO_FUSE");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
 }
 Switches &switches() {
@@ -363,18 +364,23 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
     for (int l = 0; l < L; ++l) {
         const int In_l = l == 0 ? In : H;
         const bool top = l == L - 1;
-        GemmArgs g{};
-        g.A = in; g.lda = In_l; g.Bm = w_ih[l]; g.ldb = In_l; g.C = gi; g.ldc = 3 * H; g.bias = b_ih[l];
-        g.M = (int)d.TB(); g.N = 3 * H; g.K = In_l; g.kchunk = In_l; g.slab_stride = 0; g.accumulate = 0;
-        g.amap = l == 0 ? ext_map(d, toff) : id_map(d);
-        g.bmap = id_map(d);
-        g.cmap = id_map(d);
-        TGRU_HIP(launch_gemm(g, true, true, 1, s));
         const bool mid = use_mid(H), stepk = use_step(B, H);
-        if (!mid && !stepk) TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
-
         FwdArgs f{};
         f.gi = gi; f.wp = wp; f.w_hh = w_hh[l]; f.b_hh = b_hh[l];
+        f.x = in; f.xmap = l == 0 ? ext_map(d, toff) : id_map(d); f.In = In_l; f.w_ih = w_ih[l]; f.b_ih = b_ih[l];
+        f.B = B; f.T = T; f.H = H;
+        const bool fused = mid && !stepk && gru_mid96_fwd_supported(f);    // that kernel computes gi itself
+        if (!fused) {
+            GemmArgs g{};
+            g.A = in; g.lda = In_l; g.Bm = w_ih[l]; g.ldb = In_l; g.C = gi; g.ldc = 3 * H; g.bias = b_ih[l];
+            g.M = (int)d.TB(); g.N = 3 * H; g.K = In_l; g.kchunk = In_l; g.slab_stride = 0; g.accumulate = 0;
+            g.amap = f.xmap;
+            g.bmap = id_map(d);
+            g.cmap = id_map(d);
+            TGRU_HIP(launch_gemm(g, true, true, 1, s));
+        }
+        if (!mid && !stepk) TGRU_HIP(launch_pack_whh(w_hh[l], wp, nullptr, H, s));
+
         f.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         const bool need_int = !top || layout != TGRU_LAYOUT_TBF;
         f.y_int = nullptr;
@@ -390,6 +396,7 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.B = B; f.T = T; f.H = H;
         // (the packed-W_hh region of the workspace is free on this path: it holds the sync words)
         if (stepk) TGRU_HIP(launch_gru_step_fwd(f, reinterpret_cast<unsigned *>(wp), s));
+        else if (fused) TGRU_HIP(launch_gru_mid96_fwd(f, s));
         else if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
         else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;

@@ -18,7 +18,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, gemm_guarded;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded;
     void read();
     Switches() { read(); }
 };
@@ -111,6 +111,10 @@ struct FwdArgs {
     float *h_n;             // (B,H) or null
     const int *lengths;     // int32[B] or null
     int B, T, H;
+    // the layer's input and input weights, for the kernel that computes gi itself (gru_mid96.hip); the
+    // other kernels read gi only
+    const float *x; RowMap xmap; int In;
+    const float *w_ih, *b_ih;
 };
 hipError_t launch_gru_fwd(const FwdArgs &a, hipStream_t s);
 
@@ -204,6 +208,9 @@ hipError_t launch_gru_h24_bwd(const SmallBwdArgs &a, hipStream_t s);
 // 32 < H <= 128, four sequences per workgroup on 4x4x1 MFMAs (gru_mid.hip)
 bool gru_mid_supported(int H);
 hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s);
+// H = In = 96: the recurrent kernel with the input projection inside (no gi in memory)
+bool gru_mid96_fwd_supported(const FwdArgs &a);
+hipError_t launch_gru_mid96_fwd(const FwdArgs &a, hipStream_t s);
 hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s);   // db_part: one row of 4H per SEQUENCE
 
 // both weight gradients of a mid-H layer in one pass over the rows (gru_mid_wgrad.hip)
