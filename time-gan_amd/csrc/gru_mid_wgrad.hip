@@ -234,34 +234,53 @@ __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
     }
 }
 
-// out_a[i] / out_b[i] (=|+=) sum over slabs: slab = [a (na) | b (nb)]; 32 elements x 8 slab groups per workgroup
+// Workgroups [0, wblocks): out_a[i] / out_b[i] (=|+=) sum over slabs: slab = [a (na) | b (nb)]; 32 elements x 8
+// slab groups per workgroup.  Workgroups from wblocks on: the bias gradients, column sums of the per-sequence
+// partial sums db_part (rows x 4H: da_r | da_z | da_n | da_n*r): db_ih = columns 0 .. 3H-1, db_hh = columns
+// 0 .. 2H-1 and 3H .. 4H-1; 8 columns x 32 row groups per workgroup.  (One launch for both: each alone is a
+// few microseconds of launch latency around almost no work.)
 __global__ __launch_bounds__(256) void mid_wgrad_reduce_kernel(const float *slabs, long stride, int nslabs,
                                                                float *out_a, long na, float *out_b, long nb,
-                                                               int accumulate) {
-    __shared__ float part[8][32];
-    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long idx = (long)blockIdx.x * 32 + e;
-    const int per = (nslabs + 7) / 8;
-    const int c0 = grp * per, c1 = min(nslabs, c0 + per);
+                                                               int accumulate, int wblocks, const float *db_part,
+                                                               int db_rows, int H, float *db_ih, float *db_hh) {
+    __shared__ float part[256];
+    const bool bias = (int)blockIdx.x >= wblocks;
+    // weights: 32 elements x 8 slab groups; biases: 8 columns x 32 row groups (rows are many, columns few)
+    const int ne = bias ? 8 : 32, ng = 256 / ne;
+    const int e = threadIdx.x % ne, grp = threadIdx.x / ne;
+    const long idx = (long)(bias ? blockIdx.x - wblocks : blockIdx.x) * ne + e;
+    const long n = bias ? 4L * H : na + nb;
+    const float *src = bias ? db_part : slabs;
+    const long step = bias ? 4L * H : stride;
+    const int rows = bias ? db_rows : nslabs;
+    const int per = (rows + ng - 1) / ng;
+    const int c0 = grp * per, c1 = min(rows, c0 + per);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    if (idx < na + nb) {
+    if (idx < n) {
         int c = c0;
         for (; c + 3 < c1; c += 4) {
-            v0 += slabs[(long)c * stride + idx];
-            v1 += slabs[(long)(c + 1) * stride + idx];
-            v2 += slabs[(long)(c + 2) * stride + idx];
-            v3 += slabs[(long)(c + 3) * stride + idx];
+            v0 += src[(long)c * step + idx];
+            v1 += src[(long)(c + 1) * step + idx];
+            v2 += src[(long)(c + 2) * step + idx];
+            v3 += src[(long)(c + 3) * step + idx];
         }
-        for (; c < c1; ++c) v0 += slabs[(long)c * stride + idx];
+        for (; c < c1; ++c) v0 += src[(long)c * step + idx];
     }
-    part[grp][e] = (v0 + v1) + (v2 + v3);
+    part[grp * ne + e] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (grp != 0 || idx >= na + nb) return;
+    if (grp != 0 || idx >= n) return;
     float v = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) v += part[g][e];
-    float *o = idx < na ? out_a + idx : out_b + (idx - na);
-    *o = accumulate ? *o + v : v;
+    for (int g = 0; g < ng; ++g) v += part[g * ne + e];
+    if (!bias) {
+        float *o = idx < na ? out_a + idx : out_b + (idx - na);
+        *o = accumulate ? *o + v : v;
+    } else if (idx < 3 * H) {
+        db_ih[idx] = accumulate ? db_ih[idx] + v : v;
+        if (idx < 2 * H) db_hh[idx] = accumulate ? db_hh[idx] + v : v;
+    } else {
+        const long j = idx - H;                    // column 2H + (idx - 3H)
+        db_hh[j] = accumulate ? db_hh[j] + v : v;
+    }
 }
 
 // Shapes the kernel covers: the parts of a stage must fill whole 64-lane load instructions
@@ -282,7 +301,8 @@ long gru_mid_wgrad_slab_floats(int In, int H) { return 3L * H * (In + H); }
 
 hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
                                 const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
-                                int accumulate, hipStream_t s) {
+                                int accumulate, const float *db_part, int db_rows, float *db_ih, float *db_hh,
+                                hipStream_t s) {
     MidWgradArgs a{};
     a.dg = dg; a.xin = xin; a.In = In; a.x_bt = x_bt; a.y = y; a.h0 = h0; a.slabs = slabs;
     a.slab_stride = gru_mid_wgrad_slab_floats(In, H);
@@ -309,8 +329,9 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long na = 3L * H * In, nb = 3L * H * H;
-    TGRU_LAUNCH(mid_wgrad_reduce_kernel, dim3((unsigned)((na + nb + 31) / 32)), dim3(256), 0, s, slabs,
-                       a.slab_stride, used, dw_ih, na, dw_hh, nb, accumulate);
+    const int wblocks = (int)((na + nb + 31) / 32), bblocks = db_part ? (4 * H + 7) / 8 : 0;
+    TGRU_LAUNCH(mid_wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, s, slabs, a.slab_stride, used,
+                dw_ih, na, dw_hh, nb, accumulate, wblocks, db_part, db_rows, H, db_ih, db_hh);
     return hipGetLastError();
 }
 

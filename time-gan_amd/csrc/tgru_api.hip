@@ -567,15 +567,15 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, s));
         else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
         else TGRU_HIP(launch_gru_bwd(b, s));
-        TGRU_HIP(launch_bias_grad(dbp, stepk ? gru_step_bias_rows(B) : mid ? B : nblk, H, db_ih[l], db_hh[l],
-                                  accumulate, s));
-
         const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&
                                !(l == 0 && layout == TGRU_LAYOUT_PACKED);
-        if (mid_wgrad) {
+        const int db_rows = stepk ? gru_step_bias_rows(B) : mid ? B : nblk;
+        if (mid_wgrad) {       // the weight-gradient reduction sums the bias partials in the same launch
             TGRU_HIP(launch_gru_mid_wgrad(dg, in, In_l, l == 0 && layout == TGRU_LAYOUT_BTF, y_l,
                                           h0 ? h0 + (size_t)l * B * H : nullptr, slabs, dw_ih[l], dw_hh[l], B, T,
-                                          H, accumulate, s));
+                                          H, accumulate, dbp, db_rows, db_ih[l], db_hh[l], s));
+        } else {
+            TGRU_HIP(launch_bias_grad(dbp, db_rows, H, db_ih[l], db_hh[l], accumulate, s));
         }
         // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
         if (!mid_wgrad) {

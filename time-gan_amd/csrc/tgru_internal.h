@@ -219,7 +219,8 @@ int gru_mid_wgrad_workgroups(int B, int T);
 long gru_mid_wgrad_slab_floats(int In, int H);
 hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
                                 const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
-                                int accumulate, hipStream_t s);
+                                int accumulate, const float *db_part, int db_rows, float *db_ih, float *db_hh,
+                                hipStream_t s);   // db_part (or null): the bias gradients are summed in the same launch
 
 // H > 128, H % 32 == 0: one launch per time step, 128 sequences x 32 units per workgroup (gru_step.hip).
 // Forward reads the state of step t-1 back from a.y_int (or from a.y_ext when that is time-major);
