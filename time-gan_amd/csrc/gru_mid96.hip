@@ -242,6 +242,254 @@ __global__ __launch_bounds__(64 * m96::kWaves) void gru_mid96_fwd_kernel(FwdArgs
     FSTAMP_FLUSH
 }
 
+// ----------------------------------------------------------------------------------------------
+// Backward recurrent kernel for H = In = 96 with dX = dgi . W_ih inside it.
+//
+// gru_mid.hip's backward kernel writes dg = (da_r | da_z | da_n | da_n*r) for the weight-gradient kernel and
+// for a GEMM that forms the gradient of the layer's input.  Here a second set of four matrix waves holds the
+// columns of W_ih as the first holds those of W_hh and multiplies the step's (da_r, da_z, da_n) beside the
+// recurrent product W_hh^T . (da_r, da_z, da_n*r): the same shape, the same code.  Its result goes through
+// LDS like the recurrent one: the elementwise phase of the NEXT step adds the per-gate parts and stores the
+// row of dX (the last row after the loop).
+//
+// Waves: 0-3 recurrent product + elementwise phase, 4-7 input-gradient product (4 and 5 also elementwise: 384
+// (sequence, unit) pairs, one per thread of waves 0-5), 8 loader (saved gates, h_{t-1}, dy; direct-to-LDS,
+// four steps ahead; it alone loads, so its load counter is exact).  Nine waves: three on one SIMD, 168 VGPRs.
+// Per step: [0-5: gate gradients of step t, dX row of step t+1] -> barrier A -> [0-3: W_hh^T . dgh | 4-7:
+// W_ih^T . dgi] -> barrier B.
+//
+// Products: the 3 x 96 (gate, unit) output rows are four and a half 64-row slices; wave w takes rows 64w ..
+// 64w + 63 of the flattened (gate, unit) list (one column of the matrix per lane: 96 VGPRs) and a share of
+// the last 32 (gate 2, units 64-95): contraction indices [24w, 24w + 24), lanes 0-31 the first twelve, lanes
+// 32-63 the second twelve.
+// ----------------------------------------------------------------------------------------------
+namespace m96 {
+constexpr int kBwdWaves = 9;
+constexpr int kAhead = 4, kSlots = kAhead + 1;
+constexpr int NIG = 4 * H / 64, NIY = (H + 63) / 64, NIB = NIG + 2 * NIY;    // loads per step: gates, h_{t-1}, dy
+constexpr int RS = 128;                                                        // stride of a (gate, sequence) row of parts
+constexpr int kParts = 3 * kSeq * RS + 4 * kSeq * 32;                          // [3][kSeq][RS] | shared rows [4 waves][kSeq][32]
+constexpr int kOOB = 0x7ffffff0;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void lds_load_b128(__amdgpu_buffer_rsrc_t r, float *lds, int off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, off, 0, 0, 0);
+}
+}  // namespace m96
+
+__global__ __launch_bounds__(64 * m96::kBwdWaves) void gru_mid96_bwd_kernel(BwdArgs a) {
+    using namespace m96;
+    // ops[kSlots][NIB*256] | dgs[kSeq][4][HS] (da_r, da_z, da_n*r, da_n) | parts of W_hh^T.dgh | parts of W_ih^T.dgi
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int B = a.B, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *ops = smem;
+    float *dgs = ops + kSlots * NIB * 256;
+    float *part = dgs + kSeq * 4 * HS;
+    float *dpart = part + kParts;
+    const int b0 = blockIdx.x * kSeq;
+    const long plane = (long)T * B * H;
+
+    if (wave == kBwdWaves - 1) {
+        // ---- loader: step k handles time t = T-1-k ----------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gates, 4 * plane * 4);
+        const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y_int, plane * 4);
+        const float *dyp = a.dy_int ? a.dy_int : a.dy_ext;
+        const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyp, plane * 4);
+        const bool dy_bt = !a.dy_int && a.dymap.mode == 1;              // caller's dy is (B,T,H)
+        auto issue = [&](int k) {
+            const int t = T - 1 - k;
+            float *slot = ops + (k % kSlots) * NIB * 256;
+#pragma unroll
+            for (int i = 0; i < NIG; ++i) {
+                const int e = (i * 64 + lane) * 4;          // element of the flattened [4 planes][kSeq][H] block
+                const int q = e / (kSeq * H), rem = e - q * kSeq * H;
+                const int j = rem / H, off = rem - j * H;
+                const bool ok = t >= 0 && q < 4 && b0 + j < B;
+                lds_load_b128(rs_g, slot + i * 256, ok ? (int)(q * plane * 4) + ((t * B + b0 + j) * H + off) * 4 : kOOB);
+            }
+#pragma unroll
+            for (int i = 0; i < NIY; ++i) {
+                const int e = (i * 64 + lane) * 4;          // element of a [kSeq][H] block
+                const int j = e / H, off = e - j * H;
+                const bool ok = t >= 0 && j < kSeq && b0 + j < B;
+                lds_load_b128(rs_y, slot + (NIG + i) * 256, (ok && t > 0) ? (((t - 1) * B + b0 + j) * H + off) * 4 : kOOB);
+                const int drow = dy_bt ? (b0 + j) * T + t : t * B + b0 + j;
+                lds_load_b128(rs_dy, slot + (NIG + NIY + i) * 256, ok ? (drow * H + off) * 4 : kOOB);
+            }
+        };
+        for (int k = 0; k < kAhead; ++k) issue(k);
+        wait_vmcnt<(kAhead - 1) * NIB>();
+        lds_barrier();
+        for (int k = 0; k < T; ++k) {
+            issue(k + kAhead);
+            lds_barrier();                        // A: end of the elementwise phase
+            wait_vmcnt<(kAhead - 1) * NIB>();     // operands of step k+1 have landed
+            lds_barrier();                        // B: end of the matrix phase
+        }
+        wait_vmcnt<0>();
+        lds_barrier();                            // the last dX row is stored after this one
+        return;
+    }
+
+    // ---- matrix waves: column `ucol` of gate block g of W_hh (waves 0-3) or W_ih (waves 4-7) per lane --------
+    const bool is_dx = wave >= 4;
+    const int mw = wave & 3;
+    const int flat = mw * 64 + lane;                      // row of the flattened (gate, unit) list
+    const int g = flat / H, ucol = flat - g * H;
+    const int kx = 24 * mw + 12 * (lane >> 5);            // shared rows: gate 2, unit 64 + (lane & 31), index kx .. kx + 11
+    float w[H], wx[12];
+    {
+        const float *mat = is_dx ? a.w_ih : a.w_hh;       // both (3H, 96) row-major
+        const float *src = mat + (long)g * H * H + ucol;
+#pragma unroll
+        for (int i = 0; i < H; ++i) w[i] = src[(long)i * H];
+        const float *srx = mat + ((long)2 * H + kx) * H + 64 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) wx[e] = srx[(long)e * H];
+    }
+    const int jl = lane & 3, bl = lane >> 2;
+    // out = M^T . (the three gate-gradient vectors of each sequence); vn: which vector stands for gate 2
+    // (2: da_n*r for the recurrent product, 3: da_n for the input gradient)
+    auto product = [&](int vn, float *out) {
+        const int fb = mw * 64 + 4 * bl, gb = fb / H, ub = fb - gb * H;      // this 4-lane block's rows
+        const float *v = dgs + (jl * 4 + (gb == 2 ? vn : gb)) * HS;
+        const float *vx = dgs + (jl * 4 + vn) * HS + kx;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, ax0 = acc0, ax1 = acc0;
+        constexpr int NQ = H / 4 + 3, kRing = 4;
+        float4 ring[kRing];
+        auto piece = [&](int q) {
+            return *reinterpret_cast<const float4 *>(q < H / 4 ? v + 4 * q : vx + 4 * (q - H / 4));
+        };
+#pragma unroll
+        for (int q = 0; q < kRing - 1; ++q) ring[q] = piece(q);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + kRing - 1 < NQ) ring[(q + kRing - 1) % kRing] = piece(q + kRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 x = ring[q % kRing];
+            if (q < H / 4) {
+                acc0 = mfma4(w[4 * q], x.x, acc0);
+                acc1 = mfma4(w[4 * q + 1], x.y, acc1);
+                acc0 = mfma4(w[4 * q + 2], x.z, acc0);
+                acc1 = mfma4(w[4 * q + 3], x.w, acc1);
+            } else {
+                const int e = q - H / 4;
+                ax0 = mfma4(wx[4 * e], x.x, ax0);
+                ax1 = mfma4(wx[4 * e + 1], x.y, ax1);
+                ax0 = mfma4(wx[4 * e + 2], x.z, ax0);
+                ax1 = mfma4(wx[4 * e + 3], x.w, ax1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        *reinterpret_cast<float4 *>(out + (gb * kSeq + jl) * RS + ub) =
+            make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+        // lanes l and l + 32 hold the two contraction halves of units 64 + 4*(bl & 7) .. + 3 of sequence j
+        const float4 sx = make_float4(add_halves(ax0[0] + ax1[0]), add_halves(ax0[1] + ax1[1]),
+                                      add_halves(ax0[2] + ax1[2]), add_halves(ax0[3] + ax1[3]));
+        if (lane < 32) *reinterpret_cast<float4 *>(out + 3 * kSeq * RS + (mw * kSeq + jl) * 32 + 4 * bl) = sx;
+    };
+    // the sum over the three gates of a product's result for (sequence j, unit u); gate 2's shared rows come as
+    // four partial sums, added in wave order
+    auto gates_sum = [&](const float *out, int j, int u) {
+        float g2;
+        if (u >= 64) {
+            const float *px = out + 3 * kSeq * RS + j * 32 + (u - 64);
+            g2 = ((px[0] + px[kSeq * 32]) + px[2 * kSeq * 32]) + px[3 * kSeq * 32];
+        } else {
+            g2 = out[(2 * kSeq + j) * RS + u];
+        }
+        return out[(0 * kSeq + j) * RS + u] + out[(1 * kSeq + j) * RS + u] + g2;
+    };
+
+    // ---- elementwise phase: (sequence, unit) pair p = tid of waves 0-5 -----------------------------------------
+    const int tid = threadIdx.x;
+    const bool pin = tid < kSeq * H;
+    const int pj = pin ? tid / H : 0, pu = pin ? tid % H : 0;
+    const bool pok = pin && b0 + pj < B;
+    const int plen = pok ? (a.lengths ? a.lengths[b0 + pj] : T) : 0;
+    const long sb = (long)(b0 + pj) * H + pu;
+    // the gradient of h_n enters as the initial carry: steps past the length pass it through
+    float keep = (pok && a.dh_n) ? a.dh_n[sb] : 0.f;
+    const float h0v = (pok && a.h0) ? a.h0[sb] : 0.f;
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+    // row of dX for (t, this pair's sequence): caller layouts (T,B) and (B,T), or the time-major buffer below
+    const long dx_row0 = a.dxmap.mode == 1 ? (long)(b0 + pj) * T : b0 + pj;
+    const long dx_step = a.dxmap.mode == 1 ? 1 : B;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the weight loads
+    lds_barrier();
+
+    for (int k = 0; k < T; ++k) {
+        const int t = T - 1 - k;
+        const float *slot = ops + (k % kSlots) * NIB * 256;
+        if (pin) {
+            const int j = pj, u = pu;
+            const int o = j * H + u;
+            const float r = slot[o], z = slot[kSeq * H + o], n = slot[2 * kSeq * H + o], hn = slot[3 * kSeq * H + o];
+            const float hp = t > 0 ? slot[NIG * 256 + o] : h0v;
+            const float dy = slot[(NIG + NIY) * 256 + o];
+            float dhc = keep;
+            if (k > 0) {
+                if (t + 1 < plen) dhc += gates_sum(part, j, u);     // the previous step was active: W_hh^T . dgh of that step
+                if (pok) a.dx[(dx_row0 + (t + 1) * dx_step) * H + u] = gates_sum(dpart, j, u);
+            }
+            const bool on = t < plen;
+            const float d = on ? dy + dhc : 0.f;
+            const float dn = d * (1.f - z);
+            const float dzz = d * (hp - n);
+            const float an = dn * (1.f - n * n);
+            const float dar = an * hn * r * (1.f - r);
+            const float daz = dzz * z * (1.f - z);
+            const float dgn = an * r;
+            keep = on ? d * z : dhc;
+            dgs[(j * 4 + 0) * HS + u] = dar;
+            dgs[(j * 4 + 1) * HS + u] = daz;
+            dgs[(j * 4 + 2) * HS + u] = dgn;
+            dgs[(j * 4 + 3) * HS + u] = an;
+            dbs[0] += dar; dbs[1] += daz; dbs[2] += an; dbs[3] += dgn;
+            if (pok) {
+                float *dg = a.dg + ((long)t * B + b0 + j) * 4 * H + u;
+                dg[0] = dar; dg[H] = daz; dg[2 * H] = an; dg[3 * H] = dgn;
+            }
+        }
+        lds_barrier();   // A
+        if (wave < 8) product(is_dx ? 3 : 2, is_dx ? dpart : part);
+        lds_barrier();   // B
+    }
+    lds_barrier();       // (matches the loader's last one)
+    // ---- dh0, the dX row of step 0, and the per-sequence bias-gradient partial sums --------------------------
+    if (pok) {
+        const int j = pj, u = pu;
+        float dh = keep;
+        if (0 < plen) dh += gates_sum(part, j, u);
+        if (a.dh0) a.dh0[sb] = dh;
+        a.dx[dx_row0 * H + u] = gates_sum(dpart, j, u);
+        float *dbp = a.db_part + (long)(b0 + j) * 4 * H + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbp[q * H] = dbs[q];
+    }
+}
+
+bool gru_mid96_bwd_supported(const BwdArgs &a) {
+    if (switches().no_fuse || a.H != m96::H || a.In != m96::H || !a.dx || !a.w_ih) return false;
+    return a.dxmap.mode != 2;                             // packed rows: the separate product handles them
+}
+
+hipError_t launch_gru_mid96_bwd(const BwdArgs &a, hipStream_t s) {
+    using namespace m96;
+    dim3 grid((a.B + kSeq - 1) / kSeq), block(64 * kBwdWaves);
+    const size_t lds = (size_t)(kSlots * NIB * 256 + kSeq * 4 * HS + 2 * kParts) * sizeof(float);
+    TGRU_LAUNCH(gru_mid96_bwd_kernel, grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
 // The fused kernel covers H = In = 96 with input rows in (T,B) or (B,T) order (not packed rows), 31-bit byte
 // offsets into x.
 bool gru_mid96_fwd_supported(const FwdArgs &a) {

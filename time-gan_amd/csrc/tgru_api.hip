@@ -564,7 +564,12 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         b.db_part = dbp;
         b.lengths = lengths;
         b.B = B; b.T = T; b.H = H;
+        // the gradient of the layer's input: the layer below's dy (or the caller's dx)
+        float *dx_l = l == 0 ? dx : workspace + w.dyb + (size_t)(l & 1) * dyb_stride;
+        b.w_ih = w_ih[l]; b.In = In_l; b.dx = dx_l; b.dxmap = l == 0 ? ext_map(d, toff) : id_map(d);
+        const bool fused_dx = mid && !stepk && gru_mid96_bwd_supported(b);    // that kernel forms dX itself
         if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, s));
+        else if (fused_dx) TGRU_HIP(launch_gru_mid96_bwd(b, s));
         else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
         else TGRU_HIP(launch_gru_bwd(b, s));
         const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&
@@ -614,10 +619,10 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             }
         }
         // dX = dgi . W_ih  -> gradient of the layer below (or the caller's dx)
-        if (l > 0 || dx) {
+        if ((l > 0 || dx) && !fused_dx) {
             GemmArgs g{};
             g.A = dg; g.lda = 4 * H; g.Bm = w_ih[l]; g.ldb = In_l; g.bias = nullptr;
-            g.C = l == 0 ? dx : workspace + w.dyb + (size_t)(l & 1) * dyb_stride;
+            g.C = dx_l;
             g.ldc = In_l; g.M = TB; g.N = In_l; g.K = 3 * H; g.kchunk = 3 * H; g.slab_stride = 0;
             g.accumulate = 0;
             g.amap = id_map(d); g.bmap = id_map(d);

@@ -133,6 +133,9 @@ struct BwdArgs {
     float *db_part;         // (nblocks, 4H) per-workgroup column sums of dg
     const int *lengths;
     int B, T, H;
+    // the layer's input weights and the gradient of its input, for the kernel that forms dX itself
+    // (gru_mid96.hip); the other kernels leave dX to a product over dg
+    const float *w_ih; float *dx; RowMap dxmap; int In;
 };
 hipError_t launch_gru_bwd(const BwdArgs &a, hipStream_t s);
 int gru_batch_blocks(int B);
@@ -211,6 +214,9 @@ hipError_t launch_gru_mid_fwd(const FwdArgs &a, hipStream_t s);
 // H = In = 96: the recurrent kernel with the input projection inside (no gi in memory)
 bool gru_mid96_fwd_supported(const FwdArgs &a);
 hipError_t launch_gru_mid96_fwd(const FwdArgs &a, hipStream_t s);
+// H = In = 96: the backward recurrent kernel with dX = dgi . W_ih inside
+bool gru_mid96_bwd_supported(const BwdArgs &a);
+hipError_t launch_gru_mid96_bwd(const BwdArgs &a, hipStream_t s);
 hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s);   // db_part: one row of 4H per SEQUENCE
 
 // both weight gradients of a mid-H layer in one pass over the rows (gru_mid_wgrad.hip)
