@@ -1,0 +1,25 @@
+"""Per-phase shader cycles per step of the fused H=96 BACKWARD kernel (diagnostic build libtgru_stamps.so;
+the stamp slots are shared with the forward kernel, the backward launch runs last): wave 0 (recurrent product +
+elementwise) and wave 5 (input-gradient product + elementwise) of workgroup 0; C3 layer B 1024, T 24."""
+import sys, ctypes, numpy as np, torch, os
+sys.path.insert(0, '.')
+import timegan_amd as tg
+from timegan_amd import _lib
+_lib.LIB_PATH = _lib.LIB_PATH.replace('libtgru.so', os.environ.get('STAMPS_LIB', 'libtgru_stamps.so'))
+from bench import make_weights
+dev = torch.device('cuda:0')
+B, T, H, L = 1024, 24, 96, 2      # two layers: the upper one forms a dX
+r = tg.GRURunner(B, T, H, H, L, tg.LAYOUT_TBF, dev); r.set_weights(make_weights(H, H, L, dev, 1))
+x = torch.rand(T, B, H, device=dev); dy = torch.randn(T, B, H, device=dev)
+for _ in range(3):
+    r.forward(x); r.backward(dy)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+lb = _lib.lib()
+lb.tgru_debug_stamps_mid96.argtypes = [ctypes.c_void_p]
+print('rc', lb.tgru_debug_stamps_mid96(out))
+a = np.array(out[:], dtype=np.float64) / T
+names = ['0 loop top', '1 elementwise', '2 barrier A', '3 products', '4 barrier B']
+for k in range(5):
+    print(f'{names[k]:24s} wave 0 {a[k]:8.0f}   wave 5 {a[8 + k]:8.0f}  cycles/step')
+print('sum', a[:8].sum(), a[8:].sum())

@@ -426,9 +426,11 @@ __global__ __launch_bounds__(64 * m96::kBwdWaves) void gru_mid96_bwd_kernel(BwdA
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the weight loads
     lds_barrier();
 
+    FSTAMP_DECL
     for (int k = 0; k < T; ++k) {
         const int t = T - 1 - k;
         const float *slot = ops + (k % kSlots) * NIB * 256;
+        FSTAMP(0);
         if (pin) {
             const int j = pj, u = pu;
             const int o = j * H + u;
@@ -459,10 +461,15 @@ __global__ __launch_bounds__(64 * m96::kBwdWaves) void gru_mid96_bwd_kernel(BwdA
                 dg[0] = dar; dg[H] = daz; dg[2 * H] = an; dg[3 * H] = dgn;
             }
         }
+        FSTAMP(1);
         lds_barrier();   // A
+        FSTAMP(2);
         if (wave < 8) product(is_dx ? 3 : 2, is_dx ? dpart : part);
+        FSTAMP(3);
         lds_barrier();   // B
+        FSTAMP(4);
     }
+    FSTAMP_FLUSH
     lds_barrier();       // (matches the loader's last one)
     // ---- dh0, the dX row of step 0, and the per-sequence bias-gradient partial sums --------------------------
     if (pok) {
