@@ -65,9 +65,23 @@ struct MidWgradArgs {
 };
 
 // HC: H = In = HC known at compile time (LDS offsets become immediates, the edge masks fold away), 0: any shape
+#ifdef TGRU_STAMPS   // diagnostic build only: shader cycles of wave 0 of workgroup 0: prologue, stage loop, epilogue
+__device__ unsigned long long tgru_stamps_wgrad[4];
+extern "C" int tgru_debug_stamps_wgrad(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgru_stamps_wgrad), sizeof(unsigned long long) * 4);
+}
+#define WSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                       if (blockIdx.x == 0 && threadIdx.x == 0) tgru_stamps_wgrad[k] = n_ - wst_; wst_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WSTAMP_DECL unsigned long long wst_ = __builtin_amdgcn_s_memtime();
+#else
+#define WSTAMP(k)
+#define WSTAMP_DECL
+#endif
+
 template <int HC>
 __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
     using namespace midw;
+    WSTAMP_DECL
     extern __shared__ __attribute__((aligned(16))) float smem[];   // kSlots x ( as[kRows][H] | bs[kRows][W] )
     const int H = HC ? HC : a.H, In = HC ? HC : a.In, B = a.B;
     const int K = a.T * B;
@@ -202,12 +216,14 @@ __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
     lds_barrier();                                       // stage 0 has landed
     issue(kbeg + 2 * kRows, smem + 2 * stage_floats);
     read_frags(0, fa0, fb0);
+    WSTAMP(0);
     for (int sti = 0; sti < nstages; sti += 2) {
         turn(sti, fa0, fb0, fa1, fb1);
         if (sti + 1 < nstages) turn(sti + 1, fa1, fb1, fa0, fb0);
     }
     wait_vmcnt<0>();                                     // the loads past the end still target this workgroup's LDS
     mfma_drain();
+    WSTAMP(1);
 
     // ---- this job's rows of the chunk's partial [dW_ih | dW_hh]: register r of lane (kk, j) is row
     // 8*(r/4) + r%4 + 4*kk of the tile
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
             dst[(long)row * HC + col] = v;
         }
     }
+    WSTAMP(2);
 }
 
 // Workgroups [0, wblocks): out_a[i] / out_b[i] (=|+=) sum over slabs: slab = [a (na) | b (nb)]; 32 elements x 8
