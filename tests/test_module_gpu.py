@@ -248,3 +248,43 @@ def test_unsorted_lengths_raise_like_torch():
         gru(torch.zeros(3, 5, 4, device="cuda:0"), lengths=[2, 3, 5])
     with pytest.raises(RuntimeError, match="greater than 0"):
         gru(torch.zeros(3, 5, 4, device="cuda:0"), lengths=[3, 1, 0])
+
+
+@pytest.mark.parametrize("dma", [True, False])
+@pytest.mark.parametrize("B,T,In,H,L,time_major", [
+    (24, 12, 160, 160, 2, False),     # 3H = 480: the last column tile hangs over the edge; batch-major rows
+    (50, 7, 64, 224, 2, True),        # 350 rows: the last row tile hangs over; In != H
+    (40, 33, 512, 512, 1, False),     # the stress width, row count not a multiple of the tile
+])
+def test_batched_products_with_and_without_the_loader_wave(B, T, In, H, L, time_major, dma, monkeypatch):
+    """The batched products (input projection, its transpose, the split weight gradients) run on a kernel whose
+    operand tiles are fetched by a loader wave with direct-to-LDS loads; TGRU_GEMM_NO_DMA=1 keeps them on the
+    register-staged kernel.  Both against torch's CPU nn.GRU at shapes whose tiles hang over the edges."""
+    import timegan_amd as tg
+    if dma:
+        monkeypatch.delenv("TGRU_GEMM_NO_DMA", raising=False)
+    else:
+        monkeypatch.setenv("TGRU_GEMM_NO_DMA", "1")
+    tg.reload_switches()
+    try:
+        torch.manual_seed(11)
+        ref = nn.GRU(In, H, L, batch_first=not time_major)
+        ours = tg.GRU(In, H, L, batch_first=not time_major).to("cuda:0")
+        ours.load_state_dict(ref.state_dict())
+        shape = (T, B, In) if time_major else (B, T, In)
+        x = torch.rand(shape, generator=torch.Generator().manual_seed(12))
+        xr = x.clone().requires_grad_(True)
+        xo = x.clone().cuda().requires_grad_(True)
+        yr, hr = ref(xr)
+        yo, ho = ours(xo)
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(13))
+        (yr * gy).sum().backward()
+        (yo * gy.cuda()).sum().backward()
+        tag = f"B{B}T{T}In{In}H{H}L{L}{'dma' if dma else 'staged'}"
+        assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, f"{tag} y")
+        assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} dx")
+        for (name, pr_), (_, po_) in zip(ref.named_parameters(), ours.named_parameters()):
+            assert_close(po_.grad.cpu().numpy(), pr_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{tag} d{name}")
+    finally:
+        monkeypatch.delenv("TGRU_GEMM_NO_DMA", raising=False)
+        tg.reload_switches()

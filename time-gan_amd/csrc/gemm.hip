@@ -14,6 +14,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
+// Diagnostic builds only (scratch/gemm_knockout.sh): a bit mask that removes one part of the kernel at a
+// time, so that the time of what remains can be measured.  1: no operand loads inside the loop, 2: no
+// LDS refill and no barrier inside the loop, 4: no result stores, 8: no LDS
+// refill (barrier kept), 16: no barrier (refill kept); loader-wave kernel: 32: no loads after the
+// first two tiles, 64: a quarter of the products.  The results are then wrong.
+#ifndef TGRU_GEMM_KO
+#define TGRU_GEMM_KO 0
+#endif
+
 // FAST: every operand load is an unconditional 16-byte load (the launcher has checked alignment,
 // K and kchunk multiples of BK, no packed row maps, M / N multiples of 4 where they are contiguous);
 // rows and columns past the edge are clamped onto valid ones and their results are never stored.
@@ -227,18 +236,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    if (nkt > 0) {
-        if (FAST) load_fast(kbeg); else load_guarded(kbeg);
-        store_tiles(0);
-    }
-    __syncthreads();
     const int lrow = lane & 31;
     const int lk = lane >> 5;
     int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) {
-            if (FAST) load_fast(kbeg + (kt + 1) * BK); else load_guarded(kbeg + (kt + 1) * BK);
-        }
+    auto load_tile = [&](int kt) {
+        if (FAST) load_fast(kbeg + kt * BK); else load_guarded(kbeg + kt * BK);
+    };
+    auto products = [&]() {
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
             const int k = 8 * q + 4 * lk;
@@ -273,9 +277,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+    };
+    {
+        if (nkt > 0) {
+            load_tile(0);
+            store_tiles(0);
+        }
         __syncthreads();
-        cur ^= 1;
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (!(TGRU_GEMM_KO & 1) && kt + 1 < nkt) load_tile(kt + 1);
+            products();
+            if (!(TGRU_GEMM_KO & 2)) {
+                if (!(TGRU_GEMM_KO & 8) && kt + 1 < nkt) store_tiles(cur ^ 1);
+                if (!(TGRU_GEMM_KO & 16)) __syncthreads();
+                cur ^= 1;
+            }
+        }
     }
 
     // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -285,6 +302,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * 32 + lrow;
         bias[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+    if (g.cmap.mode == 0 && !g.accumulate && m0 + BM <= g.M && n0 + BN <= g.N) {
+        // whole tile inside C, rows in order: one base address per lane, everything else constant offsets
+        float *base = Cz + (long)(m0 + wm * WTM + 4 * lk) * g.ldc + (n0 + wn * WTN + lrow);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *row = base + (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if ((TGRU_GEMM_KO & 4) && acc[i][j][r] != 12345.678f) continue;
+                    row[j * 32] = acc[i][j][r] + bias[j];
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -297,6 +330,207 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + lrow;
+                if (n < g.N) {
+                    float v = acc[i][j][r] + bias[j];
+                    if ((TGRU_GEMM_KO & 4) && v != 12345.678f) continue;
+                    float *dst = Cz + crow * g.ldc + n;
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Loader-wave variant of the 128 x 128 kernel for products that qualify for unconditional 16-byte loads.
+// Moving a tile from registers into LDS (ds_write_b128) is not covered by the products of the other waves:
+// with the operand loads removed, the LDS writes alone cost the kernel a tenth of its time.  Here a fifth wave
+// fetches every tile with direct-to-LDS loads (no registers, no LDS write instructions) into a ring of three
+// slots, two k-tiles ahead; the four product waves only read LDS and multiply, and the five waves meet at one
+// barrier per k-tile.  The loader alone issues vector-memory operations inside the loop, so its vmcnt is an
+// exact count of tiles in flight, and the product waves' LDS reads wait for nothing but LDS.
+//
+// A direct-to-LDS load writes 64 consecutive 16-byte pieces, so a tile has no padding.  A k-contiguous operand
+// sits as [row][16 floats]; piece c of row r is kept at position (c + (r >> 2)) & 3 of its row, which makes the
+// 16-byte fragment reads conflict-free (a ds_read_b128 is served in groups of sixteen lanes whose rows differ
+// in r >> 2 modulo 4 where they share banks); the rotation is applied on the global side, each lane fetching
+// the piece that belongs at its LDS position.  The other kind sits as [k][128 floats] and is read 4 bytes at a
+// time, conflict-free as it stands.
+// ---------------------------------------------------------------------------------------------------------
+namespace dma {
+constexpr int BM = 128, BN = 128;
+constexpr int kSlots = 3;
+constexpr int kTileFloats = 128 * BK;                 // one operand tile
+constexpr int kSlotFloats = 2 * kTileFloats;
+constexpr int kLoadsPerTile = kTileFloats * 4 / 1024; // load instructions per operand tile (1 KiB each)
+constexpr int kThreads = 320;
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+}  // namespace dma
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
+    using namespace dma;
+    __shared__ __attribute__((aligned(1024))) float smem[kSlots * kSlotFloats];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (row tile, column tile, k slab): as in gemm_kernel
+    const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+    const int gsize = g.nslabs > 1 ? MT * NT : NT;
+    const int ngroups = g.nslabs > 1 ? g.nslabs : MT;
+    const int wid = blockIdx.x, grp = ((wid >> 3) / gsize) * 8 + (wid & 7), mem = (wid >> 3) % gsize;
+    if (grp >= ngroups) return;
+    const int tile_m = g.nslabs > 1 ? mem % MT : grp;
+    const int tile_n = g.nslabs > 1 ? mem / MT : mem;
+    const int slab = g.nslabs > 1 ? grp : 0;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = slab * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nkt = (kend - kbeg) / BK;
+
+    if (wave == 4) {
+        // ---- loader ------------------------------------------------------------------------------------
+        // Buffer offsets are 32-bit: each operand's descriptor starts at the first byte this workgroup may
+        // touch (the launcher has checked that the extent from there fits).
+        const long a_row0 = A_KC ? (g.amap.mode == 0 ? (long)m0 : 0L) : (long)kbeg;
+        const long b_row0 = B_KC ? (long)n0 : (long)kbeg;
+        const __amdgpu_buffer_rsrc_t rs_a =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + a_row0 * g.lda), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.Bm + b_row0 * g.ldb), 0, -1, 0x00020000);
+        int va[kLoadsPerTile], vb[kLoadsPerTile];
+#pragma unroll
+        for (int i = 0; i < kLoadsPerTile; ++i) {
+            if (A_KC) {
+                const int r = i * 16 + (lane >> 2), c = ((lane & 3) - (r >> 2)) & 3;
+                const long row = map_row(g.amap, min(m0 + r, g.M - 1)) - a_row0;
+                va[i] = (int)(row * g.lda * 4) + c * 16;
+            } else {
+                va[i] = (int)((2 * i + (lane >> 5)) * g.lda * 4) + min(m0 + 4 * (lane & 31), g.M - 4) * 4;
+            }
+            if (B_KC) {
+                const int r = i * 16 + (lane >> 2), c = ((lane & 3) - (r >> 2)) & 3;
+                vb[i] = (int)((long)(min(n0 + r, g.N - 1) - n0) * g.ldb * 4) + c * 16;
+            } else {
+                vb[i] = (int)((2 * i + (lane >> 5)) * g.ldb * 4) + min(n0 + 4 * (lane & 31), g.N - 4) * 4;
+            }
+        }
+        auto issue = [&](int kt) {
+            float *slot = smem + (kt % kSlots) * kSlotFloats;
+            const int sa = A_KC ? (kbeg + kt * BK) * 4 : (int)((long)kt * BK * g.lda * 4);
+            const int sb = B_KC ? (kbeg + kt * BK) * 4 : (int)((long)kt * BK * g.ldb * 4);
+#pragma unroll
+            for (int i = 0; i < kLoadsPerTile; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void *)(slot + i * 256), 16, va[i], sa, 0, 0);
+#pragma unroll
+            for (int i = 0; i < kLoadsPerTile; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void *)(slot + kTileFloats + i * 256), 16, vb[i], sb, 0, 0);
+        };
+        if (nkt > 0) issue(0);
+        if (nkt > 1) issue(1);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) wait_vmcnt<2 * kLoadsPerTile>(); else wait_vmcnt<0>();   // tile kt has landed
+            lds_barrier();                       // the product waves may read it, and are done with tile kt - 1
+            if (!(TGRU_GEMM_KO & 32) && kt + 2 < nkt) issue(kt + 2);     // into the slot tile kt - 1 was in
+        }
+        return;
+    }
+
+    // ---- product waves: 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles ---------------------------------------------
+    // A workgroup of five waves caps a wave at 256 registers, and the compiler then keeps the accumulators in
+    // the vector half of the register file; an operand with the accumulator-register constraint makes it use
+    // the accumulator half for them, as it does in the 256-thread kernel.
+    { float z = 0.f; asm volatile("" ::"a"(z)); }
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // float offsets of this lane's fragments inside an operand tile (chunk q adds to them)
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + lrow, n = wn * 64 + i * 32 + lrow;
+        fa[i] = A_KC ? m * BK : m;
+        fb[i] = B_KC ? n * BK : n;
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        lds_barrier();
+        const float *ta = smem + (kt % kSlots) * kSlotFloats, *tb = ta + kTileFloats;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (A_KC) {
+                    const int m = wm * 64 + i * 32 + lrow;
+                    const float4 v = *reinterpret_cast<const float4 *>(ta + fa[i] + 4 * ((2 * q + lk + (m >> 2)) & 3));
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[i][e] = ta[(8 * q + 4 * lk + e) * BM + fa[i]];
+                }
+                if (B_KC) {
+                    const int n = wn * 64 + i * 32 + lrow;
+                    const float4 v = *reinterpret_cast<const float4 *>(tb + fb[i] + 4 * ((2 * q + lk + (n >> 2)) & 3));
+                    b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[i][e] = tb[(8 * q + 4 * lk + e) * BN + fb[i]];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < ((TGRU_GEMM_KO & 64) ? 1 : 4); ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *Cz = g.C + (long)slab * g.slab_stride;
+    float bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lrow;
+        bias[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+    if (g.cmap.mode == 0 && !g.accumulate && m0 + BM <= g.M && n0 + BN <= g.N) {
+        // whole tile inside C, rows in order: one base address per lane, everything else constant offsets
+        float *base = Cz + (long)(m0 + wm * 64 + 4 * lk) * g.ldc + (n0 + wn * 64 + lrow);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *row = base + (long)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) row[j * 32] = acc[i][j][r] + bias[j];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m >= g.M) continue;
+            const long crow = map_row(g.cmap, m);
+            if (crow < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + lrow;
                 if (n < g.N) {
                     float v = acc[i][j][r] + bias[j];
                     float *dst = Cz + crow * g.ldc + n;
@@ -320,6 +554,31 @@ static bool fast_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
     if (!a_kc && ((g.M & 3) || g.M < 4)) return false;
     if (!b_kc && ((g.N & 3) || g.N < 4)) return false;
     return true;
+}
+
+// The loader-wave kernel addresses its operands through buffer descriptors with 32-bit byte offsets: from the
+// first row a workgroup may touch, everything it loads must lie within 2 GiB.
+static bool dma_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
+    if (switches().gemm_no_dma) return false;
+    const long lim = 1L << 31;
+    const long kext = nslabs > 1 ? g.kchunk : g.K;
+    const long a_ext = a_kc ? (g.amap.mode == 0 ? (long)dma::BM : (long)g.M) * g.lda * 4 : kext * g.lda * 4;
+    const long b_ext = b_kc ? (long)dma::BN * g.ldb * 4 : kext * g.ldb * 4;
+    return a_ext < lim && b_ext < lim && (long)g.K * 4 < lim;
+}
+
+static hipError_t launch_dma(const GemmArgs &g0, bool a_kc, bool b_kc, int nslabs, hipStream_t s) {
+    GemmArgs g = g0;
+    g.nslabs = nslabs;
+    const long MT = (g.M + dma::BM - 1) / dma::BM, NT = (g.N + dma::BN - 1) / dma::BN;
+    const long gsize = nslabs > 1 ? MT * NT : NT, ngroups = nslabs > 1 ? nslabs : MT;
+    dim3 grid((unsigned)(8 * ((ngroups + 7) / 8) * gsize));
+    dim3 block(dma::kThreads);
+    if (a_kc && b_kc) TGRU_LAUNCH((gemm_dma_kernel<true, true>), grid, block, 0, s, g);
+    else if (a_kc && !b_kc) TGRU_LAUNCH((gemm_dma_kernel<true, false>), grid, block, 0, s, g);
+    else if (!a_kc && !b_kc) TGRU_LAUNCH((gemm_dma_kernel<false, false>), grid, block, 0, s, g);
+    else TGRU_LAUNCH((gemm_dma_kernel<false, true>), grid, block, 0, s, g);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>
@@ -351,6 +610,7 @@ hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipS
     const bool fast = fast_loads(g, a_kc, b_kc, nslabs);
     if (narrow) return fast ? launch_cfg<128, 32, 4, 1, true>(g, a_kc, b_kc, nslabs, s)
                             : launch_cfg<128, 32, 4, 1, false>(g, a_kc, b_kc, nslabs, s);
+    if (fast && dma_loads(g, a_kc, b_kc, nslabs)) return launch_dma(g, a_kc, b_kc, nslabs, s);
     return fast ? launch_cfg<128, 128, 2, 2, true>(g, a_kc, b_kc, nslabs, s)
                 : launch_cfg<128, 128, 2, 2, false>(g, a_kc, b_kc, nslabs, s);
 }

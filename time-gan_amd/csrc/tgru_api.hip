@@ -23,6 +23,7 @@ void Switches::read() {
     no_rows = on("TGRU_NO_ROWS");
     no_fuse = on("TGRU_NO_FUSE");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
+    gemm_no_dma = getenv("TGRU_GEMM_NO_DMA") != nullptr;
 }
 Switches &switches() {
     static Switches s;
@@ -62,6 +63,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
 //   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
+//   TGRU_GEMM_NO_DMA=1    128 x 128 products on the register-staged kernel instead of the loader-wave kernel
 bool use_small(int In, int H, int L) {
     if (H > kSmallMaxH || In > kSmallMaxIn || L > kSmallMaxL) return false;
     return !switches().force_generic;
