@@ -27,3 +27,4 @@ print('fwd sum', a[:8].sum())
 for k in range(8):
     print(f'bwd phase {k}: {a[8 + k]:7.2f} us')
 print('bwd sum', a[8:].sum())
+print('(loader-wave kernels: fwd 0 operand loads issued, 1 wait for peers + first tile, 3 products, 4 gates + stores issued, 5 arrival, 6 late stores;\n bwd 0 loads issued, 1 wait for peers + first tile, 2 products, 3 wait for the saved gates, 4 gates read + gradients into LDS, 5 stores + arrival)')

@@ -20,6 +20,7 @@
 // Workgroups are numbered so that the tiles of one XCD (every eighth workgroup) share their rows of
 // h / dg: the XCD's L2 then holds those rows plus W_hh.
 #include "tgru_internal.h"
+#include <stdlib.h>
 
 namespace tgru {
 
@@ -909,6 +910,276 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(PersistBwd s) {
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Loader-wave variant of the persistent forward kernel.  Moving an operand tile from registers into LDS
+// (ds_write_b128) is not covered by the products: the matrix pipe waits while the data crosses from the
+// register file, and with one workgroup per CU no other wave fills the gap (one MFMA per 80 cycles where the
+// pipe takes one per 64).  Here two extra waves fetch every operand tile with direct-to-LDS loads into a ring
+// of slots, ahead of the four product waves, which only read LDS, multiply and do the gate arithmetic; all
+// six waves meet at one barrier per k-tile.  The loader waves alone issue vector-memory loads inside the
+// product loop, so their vmcnt is an exact count of tiles in flight.  A loader wave also does the waiting for
+// the row tile's peers (it is the wave that loads what they hand over), so the product waves go from the
+// gates of one step straight to the barrier of the next step's first tile.
+//
+// A direct-to-LDS load writes 64 consecutive 16-byte pieces, so tiles have no padding: a k-contiguous tile
+// sits as [row][BK floats], piece c of row r at position (c + r * (BK/4) / 16) modulo BK/4 of its row, which
+// makes the 16-byte fragment reads conflict-free; the rotation is applied on the global side (each lane
+// fetches the piece that belongs at its LDS position).
+// The backward kernel keeps its register-staged tiles: built the same way (four loader waves, the saved gates
+// streamed into the ring slots that fall free under the last two k-tiles) it was no faster.  Its tiles are 40 KiB
+// per 32 products against 28 KiB per 48 here, about 1 MB per step and CU: with the products removed a step still
+// took 26 us, with the tile loads removed 34 us (21 us of products), so what bounds it is the rate at which a CU
+// takes bytes from the L2, and a loader wave does not raise that.
+// ----------------------------------------------------------------------------------------------
+namespace pd {
+constexpr int kLoaders = 2;
+constexpr int kThreads = 256 + 64 * kLoaders;
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// position (in 16-byte pieces) of piece c of row r inside its row of BK floats
+template <int BK>
+__device__ __forceinline__ int rot(int c, int r) { return (c + r * (BK / 4) / 16) & (BK / 4 - 1); }
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float *lds, int voff, int soff, int aux) {
+    if (aux) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, voff, soff, 0, kAuxSc1);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, voff, soff, 0, 0);
+}
+// one lane of a loader wave waits until `*cnt` has reached `want` (bounded, see kSpinLimit)
+__device__ __forceinline__ void loader_wait_for_peers(unsigned *cnt, unsigned want, unsigned *err, int lane) {
+    if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+}
+}  // namespace pd
+
+template <int BK>      // k-tile (32)
+__global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(PersistFwd s) {
+    using namespace pd;
+    constexpr int BN = 3 * kUnits, Q = BK / 4, LDH = kUnits + 4;
+    constexpr int kSlots = 4;                               // the tile being read, two in flight, one being refilled
+    constexpr int kATile = kRows * BK, kBTile = BN * BK, kSlot = kATile + kBTile;      // floats
+    constexpr int kRowsPerInst = 256 / BK;                  // tile rows one load instruction covers (1 KiB)
+    constexpr int kAPer = kATile / 256 / kLoaders, kBPer = kBTile / 256 / kLoaders;    // instructions per loader wave
+    constexpr int kPerTile = kAPer + kBPer;
+    static_assert(kATile % (256 * kLoaders) == 0 && kBTile % (256 * kLoaders) == 0 && 2 * kPerTile < 64, "tile split");
+    __shared__ __attribute__((aligned(1024))) float lds[kSlots * kSlot + kRows * LDH];
+    float (*Hs)[LDH] = reinterpret_cast<float (*)[LDH]>(lds + kSlots * kSlot);
+    __shared__ int Ls[kRows];      // length of each sequence of the row tile (0 for rows past the batch)
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const FwdArgs &a = s.f;
+    const int H = a.H, B = a.B, T = a.T, NT = H / kUnits;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = mt * kRows, u0 = nt * kUnits;
+    unsigned *cnt = s.sync + 1 + mt;
+    const long step_bytes = (long)B * H * 4;
+    const int nkt = H / BK;
+    if (tid < kRows) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ---- loader waves ------------------------------------------------------------------------------
+        const int l = wave - 4;
+        int va[kAPer], vb[kBPer];
+#pragma unroll
+        for (int i = 0; i < kAPer; ++i) {
+            const int r = (l * kAPer + i) * kRowsPerInst + lane / Q, p = lane % Q;
+            const int c = (p - r * Q / 16) & (Q - 1);
+            va[i] = (min(m0 + r, B - 1) * H + 4 * c) * 4;              // bytes inside one step's (B, H) block
+        }
+#pragma unroll
+        for (int i = 0; i < kBPer; ++i) {
+            const int r = (l * kBPer + i) * kRowsPerInst + lane / Q, p = lane % Q;
+            const int c = (p - r * Q / 16) & (Q - 1);
+            vb[i] = (((r >> 5) * H + u0 + (r & 31)) * H + 4 * c) * 4;   // rows of W_hh: gate * H + unit
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.w_hh, (long)3 * H * H * 4);
+        for (int t = 0; t < T; ++t) {
+            if (t > 0) loader_wait_for_peers(cnt, (unsigned)(NT * t), s.sync, lane);
+            if (t > 0 || a.h0 != nullptr) {
+                const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(t > 0 ? s.ybuf + (long)(t - 1) * B * H : a.h0, step_bytes);
+                auto issue = [&](int kt) {
+                    float *slot = lds + (kt % kSlots) * kSlot;
+#pragma unroll
+                    for (int i = 0; i < kAPer; ++i) dma16(rs_h, slot + (l * kAPer + i) * 256, va[i], kt * BK * 4, 1);
+#pragma unroll
+                    for (int i = 0; i < kBPer; ++i) dma16(rs_w, slot + kATile + (l * kBPer + i) * 256, vb[i], kt * BK * 4, 0);
+                };
+                issue(0);
+                if (nkt > 1) issue(1);
+                if (nkt > 2) issue(2);
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const int ahead = min(2, nkt - 1 - kt);          // younger tiles that may stay in flight
+                    if (ahead == 2) wait_vmcnt<2 * kPerTile>();
+                    else if (ahead == 1) wait_vmcnt<kPerTile>();
+                    else wait_vmcnt<0>();
+                    lds_barrier();                   // tile kt may be read; everybody is done with tile kt - 1
+                    if (kt + 3 < nkt) issue(kt + 3);
+                }
+            }
+            lds_barrier();                           // (the product waves' state tile is in LDS)
+            lds_barrier();                           // (their stores are done: arrival)
+        }
+        return;
+    }
+
+    // ---- product waves -----------------------------------------------------------------------------------
+    // (A wave of this workgroup may use 256 registers; the accumulators stay in the vector half, because asking for
+    // the accumulator half would leave 128 vector registers and spill.  Every fragment read here is a 16-byte read,
+    // for which the two forms run alike.)
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int u = u0 + lrow;
+    const long plane = (long)T * B * H;
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) valid |= (m0 + 32 * wave + d_row(r, lk) < B ? 1u : 0u) << r;
+    int roff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wave + d_row(r, lk), B - 1) * H + u) * 4;
+    const float b_r = a.b_hh[u], b_z = a.b_hh[H + u], b_n = a.b_hh[2 * H + u];
+    float hp[16];      // this workgroup's own tile of the state entering the step
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mc = min(m0 + 32 * wave + d_row(r, lk), B - 1);
+        hp[r] = a.h0 ? a.h0[(long)mc * H + u] : 0.f;
+    }
+    // float offsets of this lane's fragment rows inside a slot (piece position added per chunk)
+    const int ma = 32 * wave + lrow;
+    const int fa = ma * BK, fb = kATile + lrow * BK;
+    PSTAMP_DECL
+
+    for (int t = 0; t < T; ++t) {
+        PSTAMP(7);
+        float gir[16], giz[16], gin[16];
+        {
+            const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(a.gi + (long)t * B * 3 * H, 3 * step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {      // row m of gi is 3H wide: 3 * (m * H) + u
+                const int o = 3 * roff[r] - 8 * u;
+                gir[r] = ld1(rs_gi, o, 0);
+                giz[r] = ld1(rs_gi, o, H * 4);
+                gin[r] = ld1(rs_gi, o, 2 * H * 4);
+            }
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+        PSTAMP(0);
+        if (t > 0 || a.h0 != nullptr) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                lds_barrier();
+#ifdef TGRU_STAMPS
+                if (kt == 0) PSTAMP(1);      // wait for the peers and the first tile
+#endif
+                const float *slot = lds + (kt % kSlots) * kSlot;
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
+                    const int c = 2 * q + lk;
+                    const float4 av = *reinterpret_cast<const float4 *>(slot + fa + 4 * rot<BK>(c, ma));
+                    // (rows lrow, 32 + lrow, 64 + lrow of the W_hh tile share one rotation: 32 rows are a whole turn)
+                    const float *bp = slot + fb + 4 * rot<BK>(c, lrow);
+                    const float4 b0 = *reinterpret_cast<const float4 *>(bp);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * BK);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(bp + 64 * BK);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc[2], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc[2], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2.z, acc[2], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b2.w, acc[2], 0, 0, 0);
+                }
+            }
+        }
+
+        // gates and the new state of this tile; the state goes to LDS first so that it can leave as whole
+        // 128-byte lines (one 16-byte store per lane)
+        PSTAMP(3);
+        // The saved gates leave with the state: holding them in registers until after the arrival would cost
+        // sixty-four registers of the 256 a wave of this workgroup may use.
+        {
+            float *gt = a.gates ? a.gates + (long)t * B * H : nullptr;      // (absent tensors: empty descriptors)
+            const __amdgpu_buffer_rsrc_t rs_r = rsrc_opt(gt, step_bytes), rs_z = rsrc_opt(gt ? gt + plane : nullptr, step_bytes),
+                                         rs_n = rsrc_opt(gt ? gt + 2 * plane : nullptr, step_bytes),
+                                         rs_h = rsrc_opt(gt ? gt + 3 * plane : nullptr, step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int len = Ls[32 * wave + d_row(r, lk)];      // 0 for rows past the batch
+                const bool active = t < len;
+                const float ghn = acc[2][r] + b_n;
+                const float rg = fast_sigmoid(gir[r] + acc[0][r] + b_r);
+                const float zg = fast_sigmoid(giz[r] + acc[1][r] + b_z);
+                const float ng = fast_tanh(gin[r] + rg * ghn);
+                const float hnew = (1.f - zg) * ng + zg * hp[r];
+                const float yv = active ? hnew : 0.f;
+                hp[r] = yv;
+                Hs[32 * wave + d_row(r, lk)][lrow] = yv;
+                const int og = active ? roff[r] : 0x7fffffff;       // an offset beyond the block drops a lane's store
+                st1(rs_r, og, 0, rg); st1(rs_z, og, 0, zg); st1(rs_n, og, 0, ng); st1(rs_h, og, 0, ghn);
+            }
+        }
+        lds_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(s.ybuf + (long)t * B * H, step_bytes);
+#pragma unroll
+            for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
+                const int slot = tid + p * 256, row = slot >> 3, c4 = (slot & 7) << 2;
+                const float4 v = *reinterpret_cast<const float4 *>(&Hs[row][c4]);
+                // rows past the batch: an offset beyond the buffer, the store is dropped
+                const int off = m0 + row < B ? ((m0 + row) * H + u0 + c4) * 4 : 0x7fffffff;
+                st4_sc1(rs_y, off, v);
+            }
+        }
+        PSTAMP(4);
+        // every store of this workgroup issued so far is complete; then one lane tells the row tile's counter
+        // (the barrier also keeps Hs from being rewritten before every wave has read it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (t + 1 < T && tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PSTAMP(5);
+        // what no workgroup waits for: the caller's y (when it is not the exchange buffer), the saved
+        // gates and h_n.  These stores drain while the next step's products run.
+        if (a.y_ext && a.y_ext != s.ybuf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + d_row(r, lk);
+                const long er = ((valid >> r) & 1) ? map_tb(a.ymap, t, m) : -1L;
+                if (er >= 0) a.y_ext[er * H + u] = hp[r];
+            }
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs_hn = rsrc_opt(a.h_n, step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st1(rs_hn, t == Ls[32 * wave + d_row(r, lk)] - 1 ? roff[r] : 0x7fffffff, 0, hp[r]);
+        }
+        PSTAMP(6);
+    }
+    PSTAMP_FLUSH(0)
+}
+
 }  // namespace
 
 // (32-bit element offsets inside one step's rows: B * 4H must stay below 2^31)
@@ -957,7 +1228,8 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s) 
             k.mt0 = mt0;
             k.MT = min(per_launch, MT - mt0);
             k.mtx = (k.MT + 7) / 8;
-            if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
+            if (!switches().no_step_dma) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<32>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
+            else if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
             else TGRU_LAUNCH(gru_persist_fwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
         }
         return hipGetLastError();
