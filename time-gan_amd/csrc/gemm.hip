@@ -346,25 +346,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 // Loader-wave variant of the 128 x 128 kernel for products that qualify for unconditional 16-byte loads.
 // Moving a tile from registers into LDS (ds_write_b128) is not covered by the products of the other waves:
 // with the operand loads removed, the LDS writes alone cost the kernel a tenth of its time.  Here a fifth wave
-// fetches every tile with direct-to-LDS loads (no registers, no LDS write instructions) into a ring of three
-// slots, two k-tiles ahead; the four product waves only read LDS and multiply, and the five waves meet at one
-// barrier per k-tile.  The loader alone issues vector-memory operations inside the loop, so its vmcnt is an
+// fetches every tile with direct-to-LDS loads (no registers, no LDS write instructions) into a ring of slots,
+// ahead of the four product waves, which only read LDS and multiply; the five waves meet at one barrier per
+// k-tile.  Measured at the stress shapes (input projection / split weight gradient, TFLOP/s): k-tile 16 with
+// three slots 131 / 138, with four 135 / 138, k-tile 32 with three slots 133 / 140, with two 137 / 142: half
+// the barriers per product, and two workgroups per CU (64 KiB each) still cover each other's barriers.  The loader alone issues vector-memory operations inside the loop, so its vmcnt is an
 // exact count of tiles in flight, and the product waves' LDS reads wait for nothing but LDS.
 //
 // A direct-to-LDS load writes 64 consecutive 16-byte pieces, so a tile has no padding.  A k-contiguous operand
-// sits as [row][16 floats]; piece c of row r is kept at position (c + (r >> 2)) & 3 of its row, which makes the
-// 16-byte fragment reads conflict-free (a ds_read_b128 is served in groups of sixteen lanes whose rows differ
-// in r >> 2 modulo 4 where they share banks); the rotation is applied on the global side, each lane fetching
-// the piece that belongs at its LDS position.  The other kind sits as [k][128 floats] and is read 4 bytes at a
+// sits as [row][k-tile floats] = Q 16-byte pieces per row; piece c of row r is kept at position
+// (c + r * Q / 16) modulo Q of its row, which makes the 16-byte fragment reads conflict-free (a ds_read_b128 is
+// served in groups of sixteen lanes; the rows of a group that share banks then differ in their rotation); the
+// rotation is applied on the global side, each lane fetching the piece that belongs at its LDS position.  The other kind sits as [k][128 floats] and is read 4 bytes at a
 // time, conflict-free as it stands.
 // ---------------------------------------------------------------------------------------------------------
 namespace dma {
 constexpr int BM = 128, BN = 128;
-constexpr int kSlots = 3;
-constexpr int kTileFloats = 128 * BK;                 // one operand tile
+#ifndef TGRU_GEMM_DMA_BK
+#define TGRU_GEMM_DMA_BK 32
+#endif
+#ifndef TGRU_GEMM_DMA_SLOTS
+#define TGRU_GEMM_DMA_SLOTS 2
+#endif
+constexpr int DK = TGRU_GEMM_DMA_BK;                  // k-tile of this kernel
+constexpr int kSlots = TGRU_GEMM_DMA_SLOTS;           // ring slots: the tile being read + kSlots - 1 ahead
+constexpr int kAhead = kSlots - 1;
+constexpr int kTileFloats = 128 * DK;                 // one operand tile
 constexpr int kSlotFloats = 2 * kTileFloats;
 constexpr int kLoadsPerTile = kTileFloats * 4 / 1024; // load instructions per operand tile (1 KiB each)
+constexpr int kQ = DK / 4;                            // 16-byte pieces per row of a k-contiguous tile
 constexpr int kThreads = 320;
+static_assert((kAhead - 1) * 2 * kLoadsPerTile < 64, "vmcnt is a 6-bit count");
+// position of piece c of row r inside its row
+__device__ __forceinline__ int rot(int c, int r) { return (c + r * kQ / 16) & (kQ - 1); }
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N>
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = slab * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nkt = (kend - kbeg) / BK;
+    const int nkt = (kend - kbeg) / DK;
 
     if (wave == 4) {
         // ---- loader ------------------------------------------------------------------------------------
@@ -407,15 +421,15 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
         int va[kLoadsPerTile], vb[kLoadsPerTile];
 #pragma unroll
         for (int i = 0; i < kLoadsPerTile; ++i) {
+            // k-contiguous: an instruction covers 64 / kQ rows; lane -> (row, position), fetches piece c
+            const int r = i * (64 / kQ) + lane / kQ, c = ((lane % kQ) - r * kQ / 16) & (kQ - 1);
             if (A_KC) {
-                const int r = i * 16 + (lane >> 2), c = ((lane & 3) - (r >> 2)) & 3;
                 const long row = map_row(g.amap, min(m0 + r, g.M - 1)) - a_row0;
                 va[i] = (int)(row * g.lda * 4) + c * 16;
             } else {
                 va[i] = (int)((2 * i + (lane >> 5)) * g.lda * 4) + min(m0 + 4 * (lane & 31), g.M - 4) * 4;
             }
             if (B_KC) {
-                const int r = i * 16 + (lane >> 2), c = ((lane & 3) - (r >> 2)) & 3;
                 vb[i] = (int)((long)(min(n0 + r, g.N - 1) - n0) * g.ldb * 4) + c * 16;
             } else {
                 vb[i] = (int)((2 * i + (lane >> 5)) * g.ldb * 4) + min(n0 + 4 * (lane & 31), g.N - 4) * 4;
@@ -423,8 +437,8 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
         }
         auto issue = [&](int kt) {
             float *slot = smem + (kt % kSlots) * kSlotFloats;
-            const int sa = A_KC ? (kbeg + kt * BK) * 4 : (int)((long)kt * BK * g.lda * 4);
-            const int sb = B_KC ? (kbeg + kt * BK) * 4 : (int)((long)kt * BK * g.ldb * 4);
+            const int sa = A_KC ? (kbeg + kt * DK) * 4 : (int)((long)kt * DK * g.lda * 4);
+            const int sb = B_KC ? (kbeg + kt * DK) * 4 : (int)((long)kt * DK * g.ldb * 4);
 #pragma unroll
             for (int i = 0; i < kLoadsPerTile; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void *)(slot + i * 256), 16, va[i], sa, 0, 0);
@@ -432,12 +446,14 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
             for (int i = 0; i < kLoadsPerTile; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void *)(slot + kTileFloats + i * 256), 16, vb[i], sb, 0, 0);
         };
-        if (nkt > 0) issue(0);
-        if (nkt > 1) issue(1);
+#pragma unroll
+        for (int d = 0; d < kAhead; ++d)
+            if (d < nkt) issue(d);
         for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) wait_vmcnt<2 * kLoadsPerTile>(); else wait_vmcnt<0>();   // tile kt has landed
+            // tile kt has landed (up to kAhead - 1 younger tiles may stay in flight)
+            if (kAhead > 1 && kt + kAhead - 1 < nkt) wait_vmcnt<(kAhead - 1) * 2 * kLoadsPerTile>(); else wait_vmcnt<0>();
             lds_barrier();                       // the product waves may read it, and are done with tile kt - 1
-            if (!(TGRU_GEMM_KO & 32) && kt + 2 < nkt) issue(kt + 2);     // into the slot tile kt - 1 was in
+            if (!(TGRU_GEMM_KO & 32) && kt + kAhead < nkt) issue(kt + kAhead);     // into the slot tile kt - 1 was in
         }
         return;
     }
@@ -461,20 +477,20 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = wm * 64 + i * 32 + lrow, n = wn * 64 + i * 32 + lrow;
-        fa[i] = A_KC ? m * BK : m;
-        fb[i] = B_KC ? n * BK : n;
+        fa[i] = A_KC ? m * DK : m;
+        fb[i] = B_KC ? n * DK : n;
     }
     for (int kt = 0; kt < nkt; ++kt) {
         lds_barrier();
         const float *ta = smem + (kt % kSlots) * kSlotFloats, *tb = ta + kTileFloats;
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
+        for (int q = 0; q < DK / 8; ++q) {      // chunk q: eight k-steps, four per lane half
             float a[2][4], b[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (A_KC) {
                     const int m = wm * 64 + i * 32 + lrow;
-                    const float4 v = *reinterpret_cast<const float4 *>(ta + fa[i] + 4 * ((2 * q + lk + (m >> 2)) & 3));
+                    const float4 v = *reinterpret_cast<const float4 *>(ta + fa[i] + 4 * rot(2 * q + lk, m));
                     a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
                 } else {
 #pragma unroll
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
                 }
                 if (B_KC) {
                     const int n = wn * 64 + i * 32 + lrow;
-                    const float4 v = *reinterpret_cast<const float4 *>(tb + fb[i] + 4 * ((2 * q + lk + (n >> 2)) & 3));
+                    const float4 v = *reinterpret_cast<const float4 *>(tb + fb[i] + 4 * rot(2 * q + lk, n));
                     b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
                 } else {
 #pragma unroll
@@ -564,6 +580,7 @@ static bool dma_loads(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs) {
     const long kext = nslabs > 1 ? g.kchunk : g.K;
     const long a_ext = a_kc ? (g.amap.mode == 0 ? (long)dma::BM : (long)g.M) * g.lda * 4 : kext * g.lda * 4;
     const long b_ext = b_kc ? (long)dma::BN * g.ldb * 4 : kext * g.ldb * 4;
+    if ((g.K % dma::DK) || (nslabs > 1 && (g.kchunk % dma::DK))) return false;
     return a_ext < lim && b_ext < lim && (long)g.K * 4 < lim;
 }
 

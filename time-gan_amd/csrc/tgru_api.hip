@@ -132,8 +132,8 @@ int split_for(int M, int N, long K, int *kchunk) {
     if (maxs < 1) maxs = 1;
     long ns = want < maxs ? want : maxs;
     long kc = (K + ns - 1) / ns;
-    kc = (kc + 15) / 16 * 16;
-    if (kc < 16) kc = 16;
+    kc = (kc + 31) / 32 * 32;      // whole k-tiles of either GEMM kernel (16 / 32)
+    if (kc < 32) kc = 32;
     ns = (K + kc - 1) / kc;
     if (ns < 1) ns = 1;
     *kchunk = (int)kc;
