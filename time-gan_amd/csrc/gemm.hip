@@ -345,20 +345,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 // Loader-wave variant of the 128 x 128 kernel for products that qualify for unconditional 16-byte loads.
 // Moving a tile from registers into LDS (ds_write_b128) is not covered by the products of the other waves:
-// with the operand loads removed, the LDS writes alone cost the kernel a tenth of its time.  Here a fifth wave
-// fetches every tile with direct-to-LDS loads (no registers, no LDS write instructions) into a ring of slots,
-// ahead of the four product waves, which only read LDS and multiply; the five waves meet at one barrier per
-// k-tile.  Measured at the stress shapes (input projection / split weight gradient, TFLOP/s): k-tile 16 with
-// three slots 131 / 138, with four 135 / 138, k-tile 32 with three slots 133 / 140, with two 137 / 142: half
-// the barriers per product, and two workgroups per CU (64 KiB each) still cover each other's barriers.  The loader alone issues vector-memory operations inside the loop, so its vmcnt is an
+// with the operand loads removed, the LDS writes alone cost the kernel a tenth of its time.  Here two extra
+// waves fetch every tile with direct-to-LDS loads (no registers, no LDS write instructions) into a ring of
+// slots, ahead of the four product waves, which only read LDS and multiply; the six waves meet at one barrier
+// per k-tile.  The loader waves alone issue vector-memory operations inside the loop, so their vmcnt is an
 // exact count of tiles in flight, and the product waves' LDS reads wait for nothing but LDS.
+// Measured at the stress shapes (input projection / split weight gradient, TFLOP/s, one loader wave): k-tile 16
+// with three slots 131 / 138, with four 135 / 138, k-tile 32 with three slots 133 / 140, with two 137 / 142
+// (half the barriers per product, and two workgroups per CU of 64 KiB each still cover each other's barriers);
+// two loader waves instead of one: + 3 % / + 1 %, four like two.
 //
 // A direct-to-LDS load writes 64 consecutive 16-byte pieces, so a tile has no padding.  A k-contiguous operand
 // sits as [row][k-tile floats] = Q 16-byte pieces per row; piece c of row r is kept at position
 // (c + r * Q / 16) modulo Q of its row, which makes the 16-byte fragment reads conflict-free (a ds_read_b128 is
 // served in groups of sixteen lanes; the rows of a group that share banks then differ in their rotation); the
-// rotation is applied on the global side, each lane fetching the piece that belongs at its LDS position.  The other kind sits as [k][128 floats] and is read 4 bytes at a
-// time, conflict-free as it stands.
+// rotation is applied on the global side, each lane fetching the piece that belongs at its LDS position.  The
+// other kind sits as [k][128 floats] and is read 4 bytes at a time, conflict-free as it stands.
 // ---------------------------------------------------------------------------------------------------------
 namespace dma {
 constexpr int BM = 128, BN = 128;
@@ -375,8 +377,13 @@ constexpr int kTileFloats = 128 * DK;                 // one operand tile
 constexpr int kSlotFloats = 2 * kTileFloats;
 constexpr int kLoadsPerTile = kTileFloats * 4 / 1024; // load instructions per operand tile (1 KiB each)
 constexpr int kQ = DK / 4;                            // 16-byte pieces per row of a k-contiguous tile
-constexpr int kThreads = 320;
-static_assert((kAhead - 1) * 2 * kLoadsPerTile < 64, "vmcnt is a 6-bit count");
+#ifndef TGRU_GEMM_DMA_LOADERS
+#define TGRU_GEMM_DMA_LOADERS 2
+#endif
+constexpr int kLoaders = TGRU_GEMM_DMA_LOADERS;       // loader waves; each fetches its share of every tile
+constexpr int kPer = kLoadsPerTile / kLoaders;        // load instructions per loader wave and operand tile
+constexpr int kThreads = 256 + 64 * kLoaders;
+static_assert(kLoadsPerTile % kLoaders == 0 && (kAhead - 1) * 2 * kPer < 64, "vmcnt is a 6-bit count");
 // position of piece c of row r inside its row
 __device__ __forceinline__ int rot(int c, int r) { return (c + r * kQ / 16) & (kQ - 1); }
 typedef __attribute__((address_space(3))) void lds_void;
@@ -408,7 +415,8 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkt = (kend - kbeg) / DK;
 
-    if (wave == 4) {
+    if (wave >= 4) {
+        const int l = wave - 4;
         // ---- loader ------------------------------------------------------------------------------------
         // Buffer offsets are 32-bit: each operand's descriptor starts at the first byte this workgroup may
         // touch (the launcher has checked that the extent from there fits).
@@ -418,21 +426,22 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + a_row0 * g.lda), 0, -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.Bm + b_row0 * g.ldb), 0, -1, 0x00020000);
-        int va[kLoadsPerTile], vb[kLoadsPerTile];
+        int va[kPer], vb[kPer];
 #pragma unroll
-        for (int i = 0; i < kLoadsPerTile; ++i) {
+        for (int ii = 0; ii < kPer; ++ii) {
+            const int i = l * kPer + ii;
             // k-contiguous: an instruction covers 64 / kQ rows; lane -> (row, position), fetches piece c
             const int r = i * (64 / kQ) + lane / kQ, c = ((lane % kQ) - r * kQ / 16) & (kQ - 1);
             if (A_KC) {
                 const long row = map_row(g.amap, min(m0 + r, g.M - 1)) - a_row0;
-                va[i] = (int)(row * g.lda * 4) + c * 16;
+                va[ii] = (int)(row * g.lda * 4) + c * 16;
             } else {
-                va[i] = (int)((2 * i + (lane >> 5)) * g.lda * 4) + min(m0 + 4 * (lane & 31), g.M - 4) * 4;
+                va[ii] = (int)((2 * i + (lane >> 5)) * g.lda * 4) + min(m0 + 4 * (lane & 31), g.M - 4) * 4;
             }
             if (B_KC) {
-                vb[i] = (int)((long)(min(n0 + r, g.N - 1) - n0) * g.ldb * 4) + c * 16;
+                vb[ii] = (int)((long)(min(n0 + r, g.N - 1) - n0) * g.ldb * 4) + c * 16;
             } else {
-                vb[i] = (int)((2 * i + (lane >> 5)) * g.ldb * 4) + min(n0 + 4 * (lane & 31), g.N - 4) * 4;
+                vb[ii] = (int)((2 * i + (lane >> 5)) * g.ldb * 4) + min(n0 + 4 * (lane & 31), g.N - 4) * 4;
             }
         }
         auto issue = [&](int kt) {
@@ -440,18 +449,18 @@ __global__ __launch_bounds__(dma::kThreads) void gemm_dma_kernel(GemmArgs g) {
             const int sa = A_KC ? (kbeg + kt * DK) * 4 : (int)((long)kt * DK * g.lda * 4);
             const int sb = B_KC ? (kbeg + kt * DK) * 4 : (int)((long)kt * DK * g.ldb * 4);
 #pragma unroll
-            for (int i = 0; i < kLoadsPerTile; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void *)(slot + i * 256), 16, va[i], sa, 0, 0);
+            for (int i = 0; i < kPer; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void *)(slot + (l * kPer + i) * 256), 16, va[i], sa, 0, 0);
 #pragma unroll
-            for (int i = 0; i < kLoadsPerTile; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void *)(slot + kTileFloats + i * 256), 16, vb[i], sb, 0, 0);
+            for (int i = 0; i < kPer; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void *)(slot + kTileFloats + (l * kPer + i) * 256), 16, vb[i], sb, 0, 0);
         };
 #pragma unroll
         for (int d = 0; d < kAhead; ++d)
             if (d < nkt) issue(d);
         for (int kt = 0; kt < nkt; ++kt) {
             // tile kt has landed (up to kAhead - 1 younger tiles may stay in flight)
-            if (kAhead > 1 && kt + kAhead - 1 < nkt) wait_vmcnt<(kAhead - 1) * 2 * kLoadsPerTile>(); else wait_vmcnt<0>();
+            if (kAhead > 1 && kt + kAhead - 1 < nkt) wait_vmcnt<(kAhead - 1) * 2 * kPer>(); else wait_vmcnt<0>();
             lds_barrier();                       // the product waves may read it, and are done with tile kt - 1
             if (!(TGRU_GEMM_KO & 32) && kt + kAhead < nkt) issue(kt + kAhead);     // into the slot tile kt - 1 was in
         }
