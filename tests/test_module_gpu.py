@@ -176,18 +176,23 @@ def test_energy_width_with_initial_state_and_ragged_lengths(switches, batch_firs
         assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
-@pytest.mark.parametrize("family", ["persistent_tiles", "persistent_tiles_staged", "launch_per_step", "sixteen_sequences"])
+@pytest.mark.parametrize("family", ["persistent_tiles", "persistent_tiles_staged", "persistent_tiles_wide_backward",
+                                    "launch_per_step", "sixteen_sequences"])
 def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch):
     """H > 128 in multiples of 32 runs on 128-sequence x 32-unit tiles with the time loop inside the kernel
     (the workgroups of a row tile synchronise through counters; the forward kernel's operand tiles are fetched
-    by loader waves, TGRU_NO_STEP_DMA=1 stages them through registers); TGRU_NO_PERSIST=1 gives the same tiles
-    with one launch per time step, TGRU_NO_STEP=1 the 16-sequence kernels: all four on the same cases."""
+    by loader waves, TGRU_NO_STEP_DMA=1 stages them through registers; the backward kernel works on 64 x 64
+    tiles where H is a multiple of 64, TGRU_STEP_BWD_WIDE=1 keeps it on 128 x 32); TGRU_NO_PERSIST=1 gives the
+    same tiles with one launch per time step, TGRU_NO_STEP=1 the 16-sequence kernels: all on the same cases."""
     import timegan_amd as tg
     monkeypatch.delenv("TGRU_NO_STEP", raising=False)
     monkeypatch.delenv("TGRU_NO_PERSIST", raising=False)
     monkeypatch.delenv("TGRU_NO_STEP_DMA", raising=False)
+    monkeypatch.delenv("TGRU_STEP_BWD_WIDE", raising=False)
     if family == "persistent_tiles_staged":
         monkeypatch.setenv("TGRU_NO_STEP_DMA", "1")
+    elif family == "persistent_tiles_wide_backward":
+        monkeypatch.setenv("TGRU_STEP_BWD_WIDE", "1")
     elif family == "launch_per_step":
         monkeypatch.setenv("TGRU_NO_PERSIST", "1")
     elif family == "sixteen_sequences":

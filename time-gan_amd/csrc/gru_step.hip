@@ -911,6 +911,208 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(PersistBwd s) {
 }
 
 
+// The same kernel on 64-sequence x 64-unit tiles (two row blocks x two unit blocks of waves).  A backward step
+// is bound by the bytes a CU takes from the L2 (its operands are (rows + units) x 3H floats per workgroup and
+// step): the square tile reads a fifth less than the 128 x 32 one, and a row tile's hand-off group is eight
+// workgroups instead of sixteen.  Needs H to be a multiple of 64.
+template <int BK>
+__global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
+    constexpr int kRows = 64, kUnits = 64;       // (shadow the 128 x 32 geometry of the other kernels)
+    // A tiles as in the forward kernel: rows k-contiguous, 16-byte writes and 16-byte fragment reads, MFMA
+    // step j of chunk q standing for k = 8q + 4*(lane >> 5) + j; the W_hh tile is k-major as in memory
+    constexpr int LDK = BK + 4, LDB = kUnits + 4, LDH = kUnits + 4;
+    static_assert(BK % 16 == 0, "k-tile");
+    // one LDS array: the operand tiles of the products, and -- once the products of a step are done -- the
+    // four gate-gradient tiles on their way out
+    constexpr int kTileFloats = 2 * kRows * LDK + 2 * BK * LDB, kOutFloats = 4 * kRows * LDH;
+    __shared__ __attribute__((aligned(16))) float lds[kTileFloats > kOutFloats ? kTileFloats : kOutFloats];
+    float (*As)[kRows][LDK] = reinterpret_cast<float (*)[kRows][LDK]>(lds);
+    float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * kRows * LDK);
+    float (*Gs)[kRows][LDH] = reinterpret_cast<float (*)[kRows][LDH]>(lds);
+    __shared__ int Ls[kRows];      // length of each sequence of the row tile (0 for rows past the batch)
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const BwdArgs &a = s.b;
+    const int H = a.H, B = a.B, T = a.T, NT = H / kUnits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;      // this wave's row block and unit block of the tile
+    const int m0 = mt * kRows, u0 = nt * kUnits;
+    const int u = u0 + 32 * wc + lrow;
+    unsigned *cnt = s.sync + 1 + mt;
+    const long plane = (long)T * B * H;
+    const long step_bytes = (long)B * 4 * H * 4;      // one step's rows of dg
+
+    if (tid < kRows) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+    __syncthreads();
+    // byte offset of (sequence of register r, unit u) inside one step's (B, H) block, rows past the batch
+    // clamped to the last one; every per-step operand is addressed as descriptor(step) + this offset
+    int roff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wr + d_row(r, lk), B - 1) * H + u) * 4;
+    const long bh_bytes = (long)B * H * 4;
+    // the caller's dy: time-major (row t*B + b) or batch-major (row b*T + t); s.dy_rows = rows of a sequence
+    const int dy_bt = a.dymap.mode == 1;
+    float cin[16];          // d_{t+1} * z_{t+1} of this workgroup's own tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+    float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f;   // column sums over this wave's 32 sequences, all steps
+
+    constexpr int KQ = BK / 4, PA = kRows * KQ / 256, PB = BK * 16 / 256;   // float4 slots: A kRows x BK/4, B BK x 16
+    static_assert(BK * 16 % 256 == 0 && kRows * KQ % 256 == 0, "whole slots per thread");
+    int a_off[PA];   // rows past the batch are clamped (their results are never stored): no conditional loads
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+        a_off[p] = (min(m0 + row, B - 1) * 4 * H + kc) * 4;
+    }
+    const int b_k = tid >> 4, b_c = (tid & 15) << 2;     // slot p of this thread: k = b_k + 16 p
+    const float *b_src = a.w_hh + (long)b_k * H + u0 + b_c;
+    struct Regs { float4 a[PA], b[PB]; };
+    const int nkt = 3 * H / BK;
+    const int t_last = a.dh0 ? -1 : 0;
+    
+
+    for (int t = T - 1; t >= t_last; --t) {
+        // operands of the epilogue (gate gradients of step t), requested before the wait and the products
+        const int tc = max(t, 0);
+        // No load below is conditional: absent tensors have empty descriptors (their loads give 0), and
+        // which tensor a descriptor points at is decided once per step, not per element.
+        float gr[16], gz[16], gn[16], ghn[16], hp[16], dy[16];
+        {
+            const float *gt = a.gates + (long)tc * B * H;
+            const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
+                                         rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_di = rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
+            // batch-major dy: the block of step tc starts tc rows in and its sequences are T rows apart
+            const __amdgpu_buffer_rsrc_t rs_de =
+                rsrc_opt(a.dy_ext ? a.dy_ext + (dy_bt ? (long)tc * H : (long)tc * B * H) : nullptr,
+                         dy_bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes);
+            const __amdgpu_buffer_rsrc_t rs_dn = rsrc_opt(a.dh_n, bh_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                gr[r] = ld1(rs_r, roff[r], 0); gz[r] = ld1(rs_z, roff[r], 0);
+                gn[r] = ld1(rs_n, roff[r], 0); ghn[r] = ld1(rs_h, roff[r], 0);
+                hp[r] = ld1(rs_hp, roff[r], 0);
+                const int oe = dy_bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r];
+                const float e = ld1(rs_dn, roff[r], 0);
+                dy[r] = ld1(rs_di, roff[r], 0) + ld1(rs_de, oe, 0) + (tc == Ls[32 * wr + d_row(r, lk)] - 1 ? e : 0.f);
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        if (t < T - 1) {
+            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
+            // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows; B = W_hh (3H,H)
+            const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
+            auto load_tiles = [&](int k0, Regs &g) {
+                const int kcol = k0 < 2 * H ? k0 : k0 + H;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) g.a[p] = ld4_sc1(rs_dg, a_off[p] + kcol * 4);
+#pragma unroll
+                for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(b_src + (long)(k0 + 16 * p) * H);
+            };
+            auto store_tiles = [&](int buf, const Regs &g) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
+                    *reinterpret_cast<float4 *>(&As[buf][row][kc]) = g.a[p];
+                }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) *reinterpret_cast<float4 *>(&Bs[buf][b_k + 16 * p][b_c]) = g.b[p];
+            };
+            constexpr int kDepth = kPersistDepth;
+            Regs ring[kDepth];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) load_tiles(min(d, nkt - 1) * BK, ring[d]);
+            store_tiles(0, ring[0]);
+            load_tiles(min(kDepth, nkt - 1) * BK, ring[0]);
+            __syncthreads();
+            for (int kt0 = 0; kt0 < nkt; kt0 += kDepth) {
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    const int kt = kt0 + d, cur = kt & 1;
+                    if (kt < nkt) {
+                        auto product = [&](int q) {      // chunk q: eight k-steps, four per lane half
+                            const int k = 8 * q + 4 * lk;
+                            const float4 av = *reinterpret_cast<const float4 *>(&As[cur][32 * wr + lrow][k]);
+                            const float b0 = Bs[cur][k][32 * wc + lrow], b1 = Bs[cur][k + 1][32 * wc + lrow];
+                            const float b2 = Bs[cur][k + 2][32 * wc + lrow], b3 = Bs[cur][k + 3][32 * wc + lrow];
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[1], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc[1], 0, 0, 0);
+                        };
+#pragma unroll
+                        for (int q = 0; q < BK / 16; ++q) product(q);
+                        if (kt + 1 < nkt) {
+                            store_tiles(cur ^ 1, ring[(d + 1) % kDepth]);
+                            load_tiles(min(kt + 1 + kDepth, nkt - 1) * BK, ring[(d + 1) % kDepth]);
+                        }
+#pragma unroll
+                        for (int q = BK / 16; q < BK / 8; ++q) product(q);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        if (t < 0) {   // gradient of the initial state
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wr + d_row(r, lk);
+                if (m < B) a.dh0[(long)m * H + u] = cin[r] + acc[0][r] + acc[1][r];
+            }
+            break;
+        }
+
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wr + d_row(r, lk);
+            const bool active = t < Ls[row];
+            const float dhc = cin[r] + acc[0][r] + acc[1][r];
+            const float d = active ? dy[r] + dhc : 0.f;
+            const float dn = d * (1.f - gz[r]);
+            const float dzz = d * (hp[r] - gn[r]);
+            const float an = active ? dn * (1.f - gn[r] * gn[r]) : 0.f;
+            const float dar = active ? an * ghn[r] * gr[r] * (1.f - gr[r]) : 0.f;
+            const float daz = active ? dzz * gz[r] * (1.f - gz[r]) : 0.f;
+            const float dgn = active ? an * gr[r] : 0.f;
+            cin[r] = active ? d * gz[r] : dhc;
+            Gs[0][row][32 * wc + lrow] = dar; Gs[1][row][32 * wc + lrow] = daz; Gs[2][row][32 * wc + lrow] = an; Gs[3][row][32 * wc + lrow] = dgn;
+            sr += dar; sz += daz; sn += an; sg += dgn;      // (zero for ended sequences and rows past the batch)
+        }
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(a.dg + (long)t * B * 4 * H, step_bytes);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
+                    const int slot = tid + p * 256, row = slot >> 4, c4 = (slot & 15) << 2;
+                    const float4 v = *reinterpret_cast<const float4 *>(&Gs[q][row][c4]);
+                    const int off = m0 + row < B ? ((m0 + row) * 4 * H + q * H + u0 + c4) * 4 : 0x7fffffff;
+                    st4_sc1(rs_o, off, v);
+                }
+        }
+        if (t > t_last) arrive(cnt);     // (also keeps Gs from being rewritten before every wave has read it)
+    }
+    
+
+    sr += __shfl_xor(sr, 32); sz += __shfl_xor(sz, 32); sn += __shfl_xor(sn, 32); sg += __shfl_xor(sg, 32);
+    if (lk == 0) {
+        // one partial row per block of 32 sequences; this wave is the only writer of its 32 columns of it
+        float *p = a.db_part + (long)(mt * 2 + wr) * 4 * H + u;
+        p[0] = sr; p[H] = sz; p[2 * H] = sn; p[3 * H] = sg;
+    }
+}
+
+
+
 // ----------------------------------------------------------------------------------------------
 // Loader-wave variant of the persistent forward kernel.  Moving an operand tile from registers into LDS
 // (ds_write_b128) is not covered by the products: the matrix pipe waits while the data crosses from the
@@ -926,11 +1128,11 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(PersistBwd s) {
 // sits as [row][BK floats], piece c of row r at position (c + r * (BK/4) / 16) modulo BK/4 of its row, which
 // makes the 16-byte fragment reads conflict-free; the rotation is applied on the global side (each lane
 // fetches the piece that belongs at its LDS position).
-// The backward kernel keeps its register-staged tiles: built the same way (four loader waves, the saved gates
-// streamed into the ring slots that fall free under the last two k-tiles) it was no faster.  Its tiles are 40 KiB
-// per 32 products against 28 KiB per 48 here, about 1 MB per step and CU: with the products removed a step still
-// took 26 us, with the tile loads removed 34 us (21 us of products), so what bounds it is the rate at which a CU
-// takes bytes from the L2, and a loader wave does not raise that.
+// The backward kernels keep their register-staged tiles: built the same way (four loader waves, the saved gates
+// streamed into the ring slots that fall free under the last two k-tiles), on 128 x 32 tiles as on 64 x 64 ones,
+// they were no faster.  A backward k-tile is 32 - 40 KiB per 32 products against 28 KiB per 48 here, 0.8 - 1 MB
+// per step and CU: with the products removed a step still took 26 us, with the tile loads removed 34 us (21 us
+// of products) -- the loaders cannot deliver that many bytes under the products.
 // ----------------------------------------------------------------------------------------------
 namespace pd {
 constexpr int kLoaders = 2;
@@ -1180,6 +1382,7 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(Persi
     PSTAMP_FLUSH(0)
 }
 
+
 }  // namespace
 
 // (32-bit element offsets inside one step's rows: B * 4H must stay below 2^31)
@@ -1203,7 +1406,8 @@ static int cu_count() {
     return v;
 }
 
-size_t gru_step_sync_words(int B) { return 1 + (size_t)((B + kRows - 1) / kRows); }
+// (one word per row tile of the finest tiling, the backward kernel's 64-sequence tiles, + the error word)
+size_t gru_step_sync_words(int B) { return 1 + 2 * (size_t)((B + kRows - 1) / kRows); }
 
 // (the persistent kernels address one step's rows through 32-bit buffer offsets: the largest block, a step's
 // rows of dg, must stay below 2 GiB)
@@ -1260,6 +1464,21 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
         const int per_launch = cu_count() / NT;
         hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
+        if (a.H % 64 == 0 && !switches().step_bwd_wide) {
+            // 64-sequence x 64-unit tiles; an even number of row tiles, so that every block of 32 sequences the
+            // bias partial sums are indexed by gets written (a tile past the batch writes zeros)
+            const int NT2 = a.H / 64, MT2 = 2 * MT, per2 = cu_count() / NT2;
+            for (int mt0 = 0; mt0 < MT2; mt0 += per2) {
+                PersistBwd k;
+                k.b = a;
+                k.sync = sync;
+                k.mt0 = mt0;
+                k.MT = min(per2, MT2 - mt0);
+                k.mtx = (k.MT + 7) / 8;
+                TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+            }
+            return hipGetLastError();
+        }
         for (int mt0 = 0; mt0 < MT; mt0 += per_launch) {
             PersistBwd k;
             k.b = a;

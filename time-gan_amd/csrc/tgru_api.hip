@@ -20,6 +20,7 @@ void Switches::read() {
     no_step = on("TGRU_NO_STEP");
     no_persist = on("TGRU_NO_PERSIST");
     no_step_dma = on("TGRU_NO_STEP_DMA");
+    step_bwd_wide = on("TGRU_STEP_BWD_WIDE");
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
     no_fuse = on("TGRU_NO_FUSE");
@@ -63,6 +64,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_STEP=1        persistent 16-sequence kernels instead of one launch per step (gru_step.hip)
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
+//   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
 //   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
 //   TGRU_GEMM_NO_DMA=1    128 x 128 products on the register-staged kernel instead of the loader-wave kernel

@@ -18,7 +18,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, step_bwd_wide;
     void read();
     Switches() { read(); }
 };
