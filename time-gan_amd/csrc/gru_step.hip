@@ -1135,7 +1135,19 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
 // of products) -- the loaders cannot deliver that many bytes under the products.
 // ----------------------------------------------------------------------------------------------
 namespace pd {
-constexpr int kLoaders = 2;
+#ifndef TGRU_STEP_FWD_LOADERS
+#define TGRU_STEP_FWD_LOADERS 2
+#endif
+#ifndef TGRU_STEP_FWD_BK
+#define TGRU_STEP_FWD_BK 32
+#endif
+#ifndef TGRU_STEP_FWD_SLOTS
+#define TGRU_STEP_FWD_SLOTS 4
+#endif
+// (k-tile 32 x four slots x two loader waves; 64 x two slots, 32 x three slots and four loader waves measured the
+// same forward time within half a percent)
+constexpr int kLoaders = TGRU_STEP_FWD_LOADERS;
+constexpr int kFwdBK = TGRU_STEP_FWD_BK, kFwdSlots = TGRU_STEP_FWD_SLOTS;
 constexpr int kThreads = 256 + 64 * kLoaders;
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1170,12 +1182,13 @@ template <int BK>      // k-tile (32)
 __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(PersistFwd s) {
     using namespace pd;
     constexpr int BN = 3 * kUnits, Q = BK / 4, LDH = kUnits + 4;
-    constexpr int kSlots = 4;                               // the tile being read, two in flight, one being refilled
+    constexpr int kSlots = kFwdSlots;                       // the tile being read, those in flight, one being refilled
+    constexpr int kAhead = kSlots - 1, kFly = kAhead - 1;   // tiles issued ahead / still in flight when one is awaited
     constexpr int kATile = kRows * BK, kBTile = BN * BK, kSlot = kATile + kBTile;      // floats
     constexpr int kRowsPerInst = 256 / BK;                  // tile rows one load instruction covers (1 KiB)
     constexpr int kAPer = kATile / 256 / kLoaders, kBPer = kBTile / 256 / kLoaders;    // instructions per loader wave
     constexpr int kPerTile = kAPer + kBPer;
-    static_assert(kATile % (256 * kLoaders) == 0 && kBTile % (256 * kLoaders) == 0 && 2 * kPerTile < 64, "tile split");
+    static_assert(kATile % (256 * kLoaders) == 0 && kBTile % (256 * kLoaders) == 0 && kFly * kPerTile < 64, "tile split");
     __shared__ __attribute__((aligned(1024))) float lds[kSlots * kSlot + kRows * LDH];
     float (*Hs)[LDH] = reinterpret_cast<float (*)[LDH]>(lds + kSlots * kSlot);
     __shared__ int Ls[kRows];      // length of each sequence of the row tile (0 for rows past the batch)
@@ -1221,16 +1234,16 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(Persi
 #pragma unroll
                     for (int i = 0; i < kBPer; ++i) dma16(rs_w, slot + kATile + (l * kBPer + i) * 256, vb[i], kt * BK * 4, 0);
                 };
-                issue(0);
-                if (nkt > 1) issue(1);
-                if (nkt > 2) issue(2);
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d)
+                    if (d < nkt) issue(d);
                 for (int kt = 0; kt < nkt; ++kt) {
-                    const int ahead = min(2, nkt - 1 - kt);          // younger tiles that may stay in flight
-                    if (ahead == 2) wait_vmcnt<2 * kPerTile>();
-                    else if (ahead == 1) wait_vmcnt<kPerTile>();
+                    const int fly = min(kFly, nkt - 1 - kt);         // younger tiles that may stay in flight
+                    if (kFly >= 2 && fly == 2) wait_vmcnt<(kFly >= 2 ? 2 : 0) * kPerTile>();
+                    else if (kFly >= 1 && fly >= 1) wait_vmcnt<(kFly >= 1 ? 1 : 0) * kPerTile>();
                     else wait_vmcnt<0>();
                     lds_barrier();                   // tile kt may be read; everybody is done with tile kt - 1
-                    if (kt + 3 < nkt) issue(kt + 3);
+                    if (kt + kAhead < nkt) issue(kt + kAhead);
                 }
             }
             lds_barrier();                           // (the product waves' state tile is in LDS)
@@ -1432,7 +1445,7 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s) 
             k.mt0 = mt0;
             k.MT = min(per_launch, MT - mt0);
             k.mtx = (k.MT + 7) / 8;
-            if (!switches().no_step_dma) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<32>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
+            if (!switches().no_step_dma && a.H % pd::kFwdBK == 0) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<pd::kFwdBK>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
             else if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
             else TGRU_LAUNCH(gru_persist_fwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
         }
