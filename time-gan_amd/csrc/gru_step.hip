@@ -954,9 +954,16 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
     const long bh_bytes = (long)B * H * 4;
     // the caller's dy: time-major (row t*B + b) or batch-major (row b*T + t); s.dy_rows = rows of a sequence
     const int dy_bt = a.dymap.mode == 1;
-    float cin[16];          // d_{t+1} * z_{t+1} of this workgroup's own tile
+    // d_{t+1} * z_{t+1} of this wave's part of the tile.  It starts as the gradient of the final state: steps past a
+    // sequence's end pass the carry on unchanged (their gate gradients are zero), so it reaches the last valid
+    // step, where the other kernels add dh_n to dy -- one load per step and element less.
+    float cin[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cin[r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+        const int mc = min(m0 + 32 * wr + d_row(r, lk), B - 1);
+        cin[r] = a.dh_n ? a.dh_n[(long)mc * H + u] : 0.f;
+    }
+    const bool dy_ext = a.dy_ext != nullptr;      // (the launcher sends a call with both dy tensors to the 128 x 32 kernel)
     float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f;   // column sums over this wave's 32 sequences, all steps
 
     constexpr int KQ = BK / 4, PA = kRows * KQ / 256, PB = BK * 16 / 256;   // float4 slots: A kRows x BK/4, B BK x 16
@@ -985,20 +992,18 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
             const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
                                          rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
             const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
-            const __amdgpu_buffer_rsrc_t rs_di = rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
-            // batch-major dy: the block of step tc starts tc rows in and its sequences are T rows apart
-            const __amdgpu_buffer_rsrc_t rs_de =
-                rsrc_opt(a.dy_ext ? a.dy_ext + (dy_bt ? (long)tc * H : (long)tc * B * H) : nullptr,
-                         dy_bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes);
-            const __amdgpu_buffer_rsrc_t rs_dn = rsrc_opt(a.dh_n, bh_bytes);
+            // the gradient of this layer's output: the caller's dy (top layer; batch-major: the block of step tc
+            // starts tc rows in and its sequences are T rows apart) or the layer above's input gradient
+            const bool bt = dy_ext && dy_bt;
+            const __amdgpu_buffer_rsrc_t rs_d =
+                dy_ext ? rsrc_of(a.dy_ext + (bt ? (long)tc * H : (long)tc * B * H), bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes)
+                       : rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 gr[r] = ld1(rs_r, roff[r], 0); gz[r] = ld1(rs_z, roff[r], 0);
                 gn[r] = ld1(rs_n, roff[r], 0); ghn[r] = ld1(rs_h, roff[r], 0);
                 hp[r] = ld1(rs_hp, roff[r], 0);
-                const int oe = dy_bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r];
-                const float e = ld1(rs_dn, roff[r], 0);
-                dy[r] = ld1(rs_di, roff[r], 0) + ld1(rs_de, oe, 0) + (tc == Ls[32 * wr + d_row(r, lk)] - 1 ? e : 0.f);
+                dy[r] = ld1(rs_d, bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r], 0);
             }
         }
         f32x16 acc[2];
@@ -1007,16 +1012,18 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
         if (t < T - 1) {
-            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
             // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows; B = W_hh (3H,H)
             const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
-            auto load_tiles = [&](int k0, Regs &g) {
+            auto load_a = [&](int k0, Regs &g) {
                 const int kcol = k0 < 2 * H ? k0 : k0 + H;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) g.a[p] = ld4_sc1(rs_dg, a_off[p] + kcol * 4);
+            };
+            auto load_b = [&](int k0, Regs &g) {
 #pragma unroll
                 for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(b_src + (long)(k0 + 16 * p) * H);
             };
+            auto load_tiles = [&](int k0, Regs &g) { load_a(k0, g); load_b(k0, g); };
             auto store_tiles = [&](int buf, const Regs &g) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
@@ -1028,8 +1035,12 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
             };
             constexpr int kDepth = kPersistDepth;
             Regs ring[kDepth];
+            // the W_hh halves of the first tiles depend on nobody: they are requested before the wait for the peers
 #pragma unroll
-            for (int d = 0; d < kDepth; ++d) load_tiles(min(d, nkt - 1) * BK, ring[d]);
+            for (int d = 0; d < kDepth; ++d) load_b(min(d, nkt - 1) * BK, ring[d]);
+            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) load_a(min(d, nkt - 1) * BK, ring[d]);
             store_tiles(0, ring[0]);
             load_tiles(min(kDepth, nkt - 1) * BK, ring[0]);
             __syncthreads();
@@ -1477,7 +1488,7 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
         const int per_launch = cu_count() / NT;
         hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
-        if (a.H % 64 == 0 && !switches().step_bwd_wide) {
+        if (a.H % 64 == 0 && !switches().step_bwd_wide && !(a.dy_int && a.dy_ext)) {
             // 64-sequence x 64-unit tiles; an even number of row tiles, so that every block of 32 sequences the
             // bias partial sums are indexed by gets written (a tile past the batch writes zeros)
             const int NT2 = a.H / 64, MT2 = 2 * MT, per2 = cu_count() / NT2;
