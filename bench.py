@@ -416,6 +416,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # The result line is the ONLY thing on stdout: libraries that print there (RCCL writes a version banner when
+    # its first communicator is built) are sent to stderr at the file-descriptor level.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("TGRU_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["TGRU_BENCH_WATCHDOG"]), exit=True,
@@ -453,7 +457,7 @@ def main():
         """Rank 0 prints the one result line, once."""
         if rank == 0 and not printed:
             printed.append(True)
-            print(json.dumps(out), flush=True)
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     # If anything below stalls (a wedged collective, a hung probe), the headline result still reaches the
     # driver: after the deadline rank 0 prints the line with what has been measured so far, marked as
