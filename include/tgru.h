@@ -232,15 +232,19 @@ int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b,
  * (biased variance, eps inside the square root).
  *   ln0_w / ln0_b NULL: no input LayerNorm.   w2 NULL: shallow head, y = Linear1 output, dout == dmid.
  *   x (M, din), y (M, dout) row-major; weights in torch layout (out_features, in_features).
- *   Supported: din, dmid, dout <= 32 (TGRU_E_DIMS otherwise; callers keep the torch modules then).
+ *   Supported (tgru_head_supported): din, dout <= 32 and dmid <= 64 with the weights in registers; beyond
+ *   that din, dout <= 128 and dmid <= 192 with both matrices in LDS (at most 150 KB for the padded pair),
+ *   the Linear weight gradients then formed as products split over the rows.  TGRU_E_DIMS otherwise;
+ *   callers keep the torch modules then.
  *
  * tgru_head_backward recomputes the forward from x, writes dx (may be NULL) and the parameter
  * gradients into ONE flat buffer `dparams` of tgru_head_grad_floats() floats laid out as
  *      dW1 (dmid*din) | db1 (dmid) | dln0_w (din) | dln0_b (din) | dln1_w (dmid) | dln1_b (dmid) |
  *      dW2 (dout*dmid) | db2 (dout)
- * (entries of absent stages are written as zeros).  `workspace` needs
+ * (entries of absent stages are written as zeros unless accumulate == 1).  `workspace` needs
  * tgru_head_backward_workspace_bytes() bytes.  accumulate != 0 adds to dparams.
  */
+int tgru_head_supported(int din, int dmid, int dout, int deep);   /* deep: Linear2 present */
 size_t tgru_head_grad_floats(int din, int dmid, int dout);
 size_t tgru_head_backward_workspace_bytes(int M, int din, int dmid, int dout);
 int tgru_head_forward(const float *x, float *y, int M, int din, int dmid, int dout,

@@ -107,10 +107,17 @@ def test_argument_checks_of_the_struct_entry_points():
     assert lb.tgru_forward_pair(ctypes.byref(fa), ctypes.byref(fa), None) == E_NULL
     assert lb.tgru_head_forward_pair(None, ctypes.byref(ha), None) == E_NULL
     assert lb.tgru_head_forward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
-    ha.M, ha.din, ha.dmid, ha.dout = 8, 33, 8, 8                    # input wider than the kernels cover
+    ha.M, ha.din, ha.dmid, ha.dout = 8, 129, 8, 8                   # input wider than the kernels cover
     assert lb.tgru_head_forward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
-    ha.din, ha.dmid = 8, 65                                         # middle wider than the kernels cover
+    ha.din, ha.dmid = 8, 193                                        # middle wider than the kernels cover
     assert lb.tgru_head_backward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_DIMS
+    ha.din, ha.dmid = 33, 8                                         # covered since the LDS-resident kernels
+    assert lb.tgru_head_forward_pair(ctypes.byref(ha), ctypes.byref(ha), None) == E_NULL
+    assert lb.tgru_head_supported(24, 48, 24, 1) == 1 and lb.tgru_head_supported(96, 96, 28, 1) == 1
+    assert lb.tgru_head_supported(28, 192, 96, 1) == 1 and lb.tgru_head_supported(96, 1, 1, 0) == 1
+    assert lb.tgru_head_supported(96, 96, 28, 0) == 0               # no second Linear: dout must equal dmid
+    assert lb.tgru_head_supported(128, 192, 128, 1) == 0            # the padded pair of matrices exceeds the LDS budget
+    assert lb.tgru_head_backward_workspace_bytes(1024, 96, 96, 96) >= 3 * 1024 * 96 * 4
     assert lb.tgru_head_grad_floats(24, 24, 6) == 24 * 24 + 24 + 24 + 24 + 24 + 24 + 6 * 24 + 6
     jobs = (ReduceJob * 2)()
     assert lb.tgru_reduce_jobs(jobs, 0, None) == 0                  # nothing to do

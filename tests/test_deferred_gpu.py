@@ -7,9 +7,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _nets():
+def _nets(hidden=12):
     import timegan_amd as tg
-    cfg = tg.make_cfg(features=5, hidden=12, layers=2, seq_len=8, device="cuda:0")
+    cfg = tg.make_cfg(features=5, hidden=hidden, layers=2, seq_len=8, device="cuda:0")
     torch.manual_seed(21)
     return {k: m.to("cuda:0") for k, m in tg.build_networks(cfg).items()}
 
@@ -45,8 +45,9 @@ def _grads(nets, deferred, twice, freeze, zero=True):
 
 @pytest.mark.parametrize("twice", [False, True])
 @pytest.mark.parametrize("freeze", [False, True])
-def test_deferred_equals_immediate(twice, freeze):
-    nets = _nets()
+@pytest.mark.parametrize("hidden", [12, 96])      # 96: heads with the weights in LDS, four jobs per head
+def test_deferred_equals_immediate(twice, freeze, hidden):
+    nets = _nets(hidden)
     ref = _grads(nets, False, twice, freeze)
     got = _grads(nets, True, twice, freeze)
     assert ref.keys() == got.keys()

@@ -25,6 +25,18 @@ CASES = [
     (53, 30, 64, 31, True, True),           # the widest middle, odd widths around it
     (40, 16, 33, 16, True, True),           # a middle just past two tiles
     (16, 8, 16, 4, False, True),            # one tile everywhere
+    # beyond the register-resident kernels: weights in LDS, weight gradients as row-split products
+    (1024 * 24, 96, 96, 96, True, True),    # supervisor at dim_hidden 96, batch 1024
+    (1024 * 24, 96, 96, 28, True, True),    # recovery: norm + mlp(H -> H -> F)
+    (1024 * 24, 28, 96, 96, False, True),   # embedder feature MLP
+    (1024 * 24, 28, 192, 96, False, True),  # generator feature MLP: F -> 2H -> H
+    (1024 * 24, 96, 96, 96, True, False),   # norm + emb_linear / g_linear
+    (2048 * 24, 96, 1, 1, True, False),     # discriminator on a doubled batch: norm + Linear(H, 1)
+    (37, 70, 130, 45, True, True),          # ragged rows, odd widths in every position
+    (100, 128, 96, 128, True, True),        # the widest input / output
+    (53, 100, 128, 128, True, False),       # a wide head without the second Linear
+    (1, 96, 96, 96, True, True),            # a single row
+    (3000, 33, 65, 33, False, True),        # just past the narrow kernels' limits
 ]
 
 
@@ -45,6 +57,21 @@ def _torch_head(m, x):
     return h if m["lin2"] is None else m["lin2"](torch.relu(m["ln1"](h)))
 
 
+def _off_the_kink(m, x, gen, margin=1e-4):
+    """Rows whose pre-activation lies within `margin` of the ReLU kink are redrawn: two correct fp32
+    implementations may take different branches there, and with millions of pre-activations some do."""
+    if m["lin2"] is None:
+        return x
+    with torch.no_grad():
+        for _ in range(20):
+            pre = m["ln1"](m["lin1"](x if m["ln0"] is None else m["ln0"](x)))
+            near = (pre.abs() < margin).any(-1)
+            if not near.any():
+                break
+            x[near] = torch.randn(int(near.sum()), x.shape[1], generator=gen)
+    return x
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "m%d_%d_%d_%d_ln%d_deep%d" % c)
 @pytest.mark.parametrize("want_dx", [True, False])
 def test_head_matches_torch(case, want_dx):
@@ -54,7 +81,7 @@ def test_head_matches_torch(case, want_dx):
     ref = _modules(din, dmid, dout, ln0, deep, seed=M + din)
     ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(M, din, generator=g)
+    x = _off_the_kink(ref, torch.randn(M, din, generator=g), g)
     dy = torch.randn(M, dout, generator=g)
     xr = x.clone().requires_grad_(want_dx)
     xo = x.clone().to("cuda:0").requires_grad_(want_dx)
@@ -74,10 +101,10 @@ def test_head_matches_torch(case, want_dx):
 
 
 def test_head_3d_input_and_wide_fallback():
-    """(B, T, F) inputs keep their leading shape; widths beyond the kernels' limits (32 in / out,
-    64 in the middle) run the torch modules on the GPU."""
+    """(B, T, F) inputs keep their leading shape; widths beyond the kernels' limits (128 in / out,
+    192 in the middle) run the torch modules on the GPU."""
     from timegan_amd.head import head_apply, supported
-    m = _modules(6, 80, 24, False, True, seed=0)
+    m = _modules(6, 200, 24, False, True, seed=0)
     m = {k: (None if v is None else v.to("cuda:0")) for k, v in m.items()}
     x = torch.rand(4, 5, 6, device="cuda:0")
     assert not supported(x, m["lin1"], m["lin2"])
@@ -92,10 +119,14 @@ def test_head_3d_input_and_wide_fallback():
 
 
 @pytest.mark.parametrize("rows,din,dmid,dout", [(4096, 96, 96, 96), (3000, 28, 96, 96), (2500, 30, 70, 45)])
-def test_wide_head_weight_gradient_split_over_rows(rows, din, dmid, dout):
-    """Heads wider than the fused kernels: torch's modules, with the Linear weight gradients (out x in
-    products over all rows) formed by the library's row-split GEMM; everything against torch on the CPU."""
+def test_wide_head_weight_gradient_split_over_rows(rows, din, dmid, dout, monkeypatch):
+    """Heads the fused kernels do not take (here: switched off): torch's modules, with the Linear weight
+    gradients (out x in products over all rows) formed by the library's row-split GEMM and LayerNorm on the
+    library's kernels; everything against torch on the CPU."""
+    import timegan_amd as tg
     from timegan_amd.head import WIDE_LINEAR_MIN_ROWS, head_apply, supported
+    monkeypatch.setenv("TGRU_NO_WIDE_HEAD", "1")
+    tg.reload_switches()
     assert rows >= WIDE_LINEAR_MIN_ROWS
     ref = _modules(din, dmid, dout, True, True, seed=3)
     ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
@@ -154,6 +185,8 @@ PAIRS = [
     ((3072, 24, 24, 6, True, True), (6144, 24, 24, 1, True, False)),      # recovery + discriminator (doubled batch)
     ((3072, 6, 24, 24, False, True), (3072, 6, 48, 24, False, True)),     # the two feature MLPs, one of them wide
     ((37, 5, 10, 7, True, True), (20, 30, 64, 31, True, True)),
+    ((3072, 96, 96, 96, True, True), (3072, 24, 24, 24, True, False)),    # one of them beyond the paired kernels
+    ((3072, 96, 96, 28, True, True), (6144, 96, 1, 1, True, False)),      # both (issued one after the other)
 ]
 
 

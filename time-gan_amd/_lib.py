@@ -81,6 +81,7 @@ SIGNATURES = {
     "tgru_layer_norm_backward": (_i, [_vp] * 8 + [ctypes.c_long, _i, _i, _vp]),
     "tgru_linear_weight_grad_workspace_bytes": (ctypes.c_size_t, [_i] * 3),
     "tgru_linear_weight_grad": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    "tgru_head_supported": (_i, [_i] * 4),
     "tgru_head_grad_floats": (ctypes.c_size_t, [_i] * 3),
     "tgru_head_backward_workspace_bytes": (ctypes.c_size_t, [_i] * 4),
     "tgru_head_forward": (_i, [_vp] * 2 + [_i] * 4 + [_vp] * 8 + [ctypes.c_float, _vp]),

@@ -531,9 +531,12 @@ using namespace tgru;
 
 namespace {
 
+// beyond the widths of the register-resident kernels: head_wide.hip
+bool is_wide(const tgru_head_args &c) { return c.din > head::kIo || c.dout > head::kIo || c.dmid > head::kMid; }
+
 int head_check(const tgru_head_args &c, bool backward) {
     if (c.M <= 0 || c.din <= 0 || c.dmid <= 0 || c.dout <= 0) return TGRU_E_DIMS;
-    if (c.din > head::kIo || c.dout > head::kIo || c.dmid > head::kMid) return TGRU_E_DIMS;
+    if (is_wide(c) && !head_wide_supported(c.din, c.dmid, c.dout, c.w2 != nullptr)) return TGRU_E_DIMS;
     if (!c.w2 && c.dout != c.dmid) return TGRU_E_DIMS;
     if ((long long)c.M * 64 >= (1LL << 31)) return TGRU_E_DIMS;
     if (!c.w1 || !c.b1 || !c.x) return TGRU_E_NULL;
@@ -604,6 +607,14 @@ int head_forward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStrea
     int rc = head_check(*a, false);
     if (rc == TGRU_OK && b) rc = head_check(*b, false);
     if (rc != TGRU_OK) return rc;
+    if (is_wide(*a) || (b && is_wide(*b))) {     // no paired launch: one call after the other
+        const tgru_head_args *both[2] = {a, b};
+        for (int k = 0; k < 2 && both[k]; ++k) {
+            rc = is_wide(*both[k]) ? head_wide_forward(*both[k], s) : head_forward_impl(both[k], nullptr, s);
+            if (rc != TGRU_OK) return rc;
+        }
+        return TGRU_OK;
+    }
     head::Args fa{}, fb{};
     head_fill(*a, false, fa);
     if (b) head_fill(*b, false, fb);
@@ -614,6 +625,14 @@ int head_backward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStre
     int rc = head_check(*a, true);
     if (rc == TGRU_OK && b) rc = head_check(*b, true);
     if (rc != TGRU_OK) return rc;
+    if (is_wide(*a) || (b && is_wide(*b))) {
+        const tgru_head_args *both[2] = {a, b};
+        for (int k = 0; k < 2 && both[k]; ++k) {
+            rc = is_wide(*both[k]) ? head_wide_backward(*both[k], s) : head_backward_impl(both[k], nullptr, s);
+            if (rc != TGRU_OK) return rc;
+        }
+        return TGRU_OK;
+    }
     head::Args fa{}, fb{};
     head_fill(*a, true, fa);
     if (b) head_fill(*b, true, fb);
@@ -637,7 +656,15 @@ size_t tgru_head_grad_floats(int din, int dmid, int dout) {
 
 size_t tgru_head_backward_workspace_bytes(int M, int din, int dmid, int dout) {
     if (M <= 0) return 0;
+    if (din > head::kIo || dout > head::kIo || dmid > head::kMid)
+        return head_wide_workspace_floats(M, din, dmid, dout) * sizeof(float);
     return (size_t)head::workgroups(M) * head::grad_layout(din, dmid, dout).total * sizeof(float);
+}
+
+int tgru_head_supported(int din, int dmid, int dout, int deep) {
+    if (din <= 0 || dmid <= 0 || dout <= 0 || (!deep && dmid != dout)) return 0;
+    if (din <= head::kIo && dout <= head::kIo && dmid <= head::kMid) return 1;
+    return head_wide_supported(din, dmid, dout, deep != 0) ? 1 : 0;
 }
 
 int tgru_head_forward(const float *x, float *y, int M, int din, int dmid, int dout, const float *ln0_w,
@@ -665,6 +692,7 @@ int tgru_head_reduce_jobs(const tgru_head_args *c, tgru_reduce_job *jobs, int ma
     const int rc = head_check(*c, true);
     if (rc != TGRU_OK) return rc;
     if (c->accumulate != TGRU_DEFER_REDUCE) return 0;
+    if (is_wide(*c)) return head_wide_reduce_jobs(*c, jobs, max_jobs);
     if (max_jobs < 1) return TGRU_E_DIMS;
     const int total = head::grad_layout(c->din, c->dmid, c->dout).total;
     jobs[0] = tgru_reduce_job{c->workspace, (int64_t)total, head::workgroups(c->M), total, c->dparams};

@@ -24,12 +24,29 @@ void Switches::read() {
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
     no_fuse = on("TGRU_NO_FUSE");
+    no_wide_head = on("TGRU_NO_WIDE_HEAD");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
     gemm_no_dma = getenv("TGRU_GEMM_NO_DMA") != nullptr;
 }
 Switches &switches() {
     static Switches s;
     return s;
+}
+int gemm_split_for(int M, int N, long K, int *kchunk) {
+    const int bn = (N <= 96) ? 32 : 128;
+    const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
+    long want = 768 / tiles;
+    if (want < 1) want = 1;
+    long maxs = K / 512;
+    if (maxs < 1) maxs = 1;
+    long ns = want < maxs ? want : maxs;
+    long kc = (K + ns - 1) / ns;
+    kc = (kc + 31) / 32 * 32;      // whole k-tiles of either GEMM kernel (16 / 32)
+    if (kc < 32) kc = 32;
+    ns = (K + kc - 1) / kc;
+    if (ns < 1) ns = 1;
+    *kchunk = (int)kc;
+    return (int)ns;
 }
 }  // namespace tgru
 
@@ -66,6 +83,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
 //   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
+//   TGRU_NO_WIDE_HEAD=1   heads beyond 32 / 64 wide are not taken by the fused kernels of head_wide.hip
 //   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
 //   TGRU_GEMM_NO_DMA=1    128 x 128 products on the register-staged kernel instead of the loader-wave kernel
 bool use_small(int In, int H, int L) {
@@ -125,22 +143,6 @@ size_t fwd_ws_floats(const Dims &d) {
     return align64(d.TB() * 3 * d.H) + align64(packed_whh_floats(d.H)) + 2 * align64(d.TBH());
 }
 
-int split_for(int M, int N, long K, int *kchunk) {
-    const int bn = (N <= 96) ? 32 : 128;
-    const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
-    long want = 768 / tiles;
-    if (want < 1) want = 1;
-    long maxs = K / 512;
-    if (maxs < 1) maxs = 1;
-    long ns = want < maxs ? want : maxs;
-    long kc = (K + ns - 1) / ns;
-    kc = (kc + 31) / 32 * 32;      // whole k-tiles of either GEMM kernel (16 / 32)
-    if (kc < 32) kc = 32;
-    ns = (K + kc - 1) / kc;
-    if (ns < 1) ns = 1;
-    *kchunk = (int)kc;
-    return (int)ns;
-}
 
 // backward workspace: dg | 2 x dy ping-pong | packed W_hh^T | bias partials | split-K slabs
 struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, total; int max_slabs; };
@@ -160,9 +162,9 @@ BwdWs bwd_ws(const Dims &d) {
     w.dbp = off; off += align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
-    int ns = split_for(3 * d.H, widest, (long)d.TB(), &kc);
-    int ns2 = split_for(3 * d.H, d.H, (long)d.TB(), &kc);
-    int ns3 = split_for(3 * d.H, d.In, (long)d.TB(), &kc);
+    int ns = gemm_split_for(3 * d.H, widest, (long)d.TB(), &kc);
+    int ns2 = gemm_split_for(3 * d.H, d.H, (long)d.TB(), &kc);
+    int ns3 = gemm_split_for(3 * d.H, d.In, (long)d.TB(), &kc);
     w.max_slabs = ns > ns2 ? ns : ns2;
     if (ns3 > w.max_slabs) w.max_slabs = ns3;
     size_t slab_floats = (size_t)w.max_slabs * 3 * d.H * widest;
@@ -290,7 +292,7 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
 size_t tgru_linear_weight_grad_workspace_bytes(int rows, int out_f, int in_f) {
     if (rows <= 0 || out_f <= 0 || in_f <= 0) return 0;
     int kc;
-    const int ns = split_for(out_f, in_f, rows, &kc);
+    const int ns = gemm_split_for(out_f, in_f, rows, &kc);
     return (size_t)ns * out_f * in_f * sizeof(float);
 }
 
@@ -300,7 +302,7 @@ int tgru_linear_weight_grad(const float *dy, const float *x, float *dw, float *w
     if (!dy || !x || !dw || !workspace) return TGRU_E_NULL;
     if (accumulate != 0 && accumulate != 1) return TGRU_E_DIMS;
     int kc;
-    const int ns = split_for(out_f, in_f, rows, &kc);
+    const int ns = gemm_split_for(out_f, in_f, rows, &kc);
     GemmArgs g{};
     g.A = dy; g.lda = out_f; g.Bm = x; g.ldb = in_f; g.C = workspace; g.ldc = in_f; g.bias = nullptr;
     g.M = out_f; g.N = in_f; g.K = rows; g.kchunk = kc; g.slab_stride = (long)out_f * in_f; g.accumulate = 0;
@@ -591,7 +593,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
         if (!mid_wgrad) {
             int kc;
-            const int ns = split_for(3 * H, In_l, TB, &kc);
+            const int ns = gemm_split_for(3 * H, In_l, TB, &kc);
             GemmArgs g{};
             g.A = dg; g.lda = 4 * H; g.Bm = in; g.ldb = In_l; g.C = slabs; g.ldc = In_l; g.bias = nullptr;
             g.M = 3 * H; g.N = In_l; g.K = TB; g.kchunk = kc; g.slab_stride = (long)3 * H * In_l;
@@ -605,7 +607,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         if (!mid_wgrad) {
             int kc;
             const int K = TB - B;
-            const int ns = split_for(3 * H, H, K > 0 ? K : 1, &kc);
+            const int ns = gemm_split_for(3 * H, H, K > 0 ? K : 1, &kc);
             GemmArgs g{};
             g.lda = 4 * H; g.Bm = y_l; g.ldb = H; g.ldc = H; g.bias = nullptr;
             g.N = H; g.K = K; g.kchunk = kc; g.slab_stride = (long)3 * H * H; g.accumulate = 0;

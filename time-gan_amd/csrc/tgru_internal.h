@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <atomic>
 
+struct tgru_head_args;
+struct tgru_reduce_job;
+
 namespace tgru {
 
 // Process-wide count of the kernel launches the library has issued (diagnostics only: a caller reads it
@@ -18,7 +21,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, step_bwd_wide;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, step_bwd_wide, no_wide_head;
     void read();
     Switches() { read(); }
 };
@@ -90,6 +93,9 @@ hipError_t launch_gemm(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs, hipS
 // row-streaming kernel for the H = In = 96 input projection and its transpose (launch_gemm dispatches to it)
 bool rows_gemm_supported(const GemmArgs &g, bool a_kc, bool b_kc, int nslabs);
 hipError_t launch_rows_gemm(const GemmArgs &g, bool b_kc, hipStream_t s);
+
+// split-K plan of a weight-gradient product C (M x N) over K rows: number of slabs, rows per slab
+int gemm_split_for(int M, int N, long K, int *kchunk);
 
 // out[i] (=|+=) sum_z slabs[z*stride + i], i < n
 hipError_t launch_slab_reduce(const float *slabs, long stride, int nslabs, float *out, long n,
@@ -253,5 +259,13 @@ hipError_t launch_gru_vec_fwd(const SmallFwdArgs &a, const SmallFwdArgs *second,
 hipError_t launch_gru_vec_bwd(const SmallBwdArgs &a, const SmallBwdArgs *second, hipStream_t s);
 int gru_vec_workgroups(int B);
 bool gru_vec_supported(int B, int T, int In, int H, int L);
+
+// Fused heads beyond head.hip's widths (head_wide.hip): weights in LDS, weight gradients as split-K products.
+// The argument blocks are the C ABI's (include/tgru.h), checked by the caller.
+bool head_wide_supported(int din, int dmid, int dout, bool deep);
+size_t head_wide_workspace_floats(int M, int din, int dmid, int dout);
+int head_wide_forward(const ::tgru_head_args &c, hipStream_t s);
+int head_wide_backward(const ::tgru_head_args &c, hipStream_t s);   // incl. the reductions unless deferred
+int head_wide_reduce_jobs(const ::tgru_head_args &c, ::tgru_reduce_job *jobs, int max_jobs);
 
 }  // namespace tgru

@@ -1,6 +1,6 @@
 """Fused dense head of the TimeGAN networks on the GPU (libtgru.so: tgru_head_forward/backward).
 
-    y = [LayerNorm] -> Linear -> [LayerNorm -> ReLU -> Linear]    (per row; in / out <= 32 wide, middle <= 64)
+    y = [LayerNorm] -> Linear -> [LayerNorm -> ReLU -> Linear]    (per row; in / out <= 128 wide, middle <= 192)
 
 The op takes the parameters of ordinary torch modules (nn.LayerNorm, nn.Linear), so the networks
 keep torch's module structure and state_dict keys (outdated_files/TimeGANv1.py:39-50,119-128,
@@ -16,8 +16,8 @@ import torch.nn as nn
 from . import _lib, deferred
 from ._lib import HeadArgs, check, lib, on_device
 
-MAX_IO_WIDTH = 32
-MAX_MID_WIDTH = 64
+MAX_IO_WIDTH = 32       # up to here (middle: MAX_MID_WIDTH) the kernels keep the weights in registers and
+MAX_MID_WIDTH = 64      # two heads can share a launch; wider heads (tgru_head_supported) keep them in LDS
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -83,19 +83,19 @@ class _HeadFunction(torch.autograd.Function):
 
 
 def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear], lns=()) -> bool:
-    """True when the fused kernels cover this head: GPU fp32 rows, input / output at most 32 wide, the
-    middle (between the two Linears) at most 64, biases present."""
+    """True when the fused kernels cover this head: GPU fp32 rows, widths the library takes
+    (tgru_head_supported: input / output up to 128, the middle between the two Linears up to 192), biases
+    present."""
     if not x.is_cuda or x.dtype != torch.float32:
         return False
     if lin1.bias is None or (lin2 is not None and lin2.bias is None):
         return False
     if any(ln is not None and (ln.weight is None or ln.bias is None) for ln in lns):
         return False      # LayerNorm(elementwise_affine=False): the fused kernels expect gamma and beta
-    if lin1.in_features > MAX_IO_WIDTH:
+    if any(p.dtype != torch.float32 for p in (lin1.weight, lin1.bias)):
         return False
-    if lin2 is None:
-        return lin1.out_features <= MAX_IO_WIDTH
-    return lin1.out_features <= MAX_MID_WIDTH and lin2.out_features <= MAX_IO_WIDTH
+    dout = lin1.out_features if lin2 is None else lin2.out_features
+    return bool(lib().tgru_head_supported(lin1.in_features, lin1.out_features, dout, int(lin2 is not None)))
 
 
 def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
