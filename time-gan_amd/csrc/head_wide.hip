@@ -103,7 +103,7 @@ __host__ __device__ inline VecLayout vec_layout(int din, int dmid, int dout) {
 __device__ __forceinline__ void stage_matrix(float *dst, int ld, const float *w, int rows, int cols, int rows_p) {
     const int n4 = ld >> 2;
     const bool vec = (cols & 3) == 0;
-    for (int idx = threadIdx.x; idx < rows_p * n4; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < rows_p * n4; idx += blockDim.x) {
         const int r = idx / n4, c = 4 * (idx - r * n4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows) {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void stage_matrix(float *dst, int ld, const float *w,
     }
 }
 __device__ __forceinline__ void stage_vec(float *dst, const float *p, int n, int n_p) {
-    for (int i = threadIdx.x; i < n_p; i += kThreads) dst[i] = (p && i < n) ? p[i] : 0.f;
+    for (int i = threadIdx.x; i < n_p; i += blockDim.x) dst[i] = (p && i < n) ? p[i] : 0.f;
 }
 __device__ __forceinline__ void stage_params(const Args &a, const Lds &l, float *lds, bool deep) {
     stage_matrix(lds + l.w1, l.ld1, a.w1, a.dmid, a.din, rup16(a.dmid));
@@ -249,8 +249,10 @@ __device__ __forceinline__ void ln_stats(const float (&v)[4 * NT], int g, int d,
 // ----------------------------------------------------------------------------------------------
 // forward
 // ----------------------------------------------------------------------------------------------
-template <int NI, int NM, int NO>
-__global__ __launch_bounds__(kThreads) void head_wide_fwd_kernel(Args a) {
+// NW waves per workgroup: two per SIMD, so that one wave's row loads and LayerNorm chains hide under the
+// other's products
+template <int NI, int NM, int NO, int NW>
+__global__ __launch_bounds__(64 * NW) void head_wide_fwd_kernel(Args a) {
     extern __shared__ __align__(16) float lds[];
     const bool deep = a.w2 != nullptr;
     const Lds l = lds_layout(a.din, a.dmid, a.dout, deep);
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void head_wide_fwd_kernel(Args a) {
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int ntiles = (a.M + kRows - 1) / kRows;
-    for (int tile = blockIdx.x * kWaves + wave; tile < ntiles; tile += gridDim.x * kWaves) {
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
         const long row = (long)tile * kRows + j;
         float x[4 * NI];
         load_rows<NI>(a.x, a.M, a.din, row, g, a.vec_in, x);
@@ -457,8 +459,9 @@ size_t lds_bytes(int din, int dmid, int dout, bool deep, bool backward) {
     return b;
 }
 
-int workgroups(int M) {
-    const int groups = ((M + kRows - 1) / kRows + kWaves - 1) / kWaves;
+constexpr int kFwdWaves = 8;
+int workgroups(int M, int waves = kWaves) {
+    const int groups = ((M + kRows - 1) / kRows + waves - 1) / waves;
     return groups < 256 ? groups : 256;
 }
 
@@ -486,16 +489,18 @@ hipError_t launch(const Args &a, bool backward, hipStream_t s) {
     const bool deep = a.w2 != nullptr;
     const size_t lds = lds_bytes<NI, NM, NO>(a.din, a.dmid, a.dout, deep, backward);
     const void *fn = backward ? reinterpret_cast<const void *>(head_wide_bwd_kernel<NI, NM, NO>)
-                              : reinterpret_cast<const void *>(head_wide_fwd_kernel<NI, NM, NO>);
+                              : reinterpret_cast<const void *>(head_wide_fwd_kernel<NI, NM, NO, kFwdWaves>);
     static bool raised[2] = {false, false};       // per template instance and direction
     if (!raised[backward]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
         if (e != hipSuccess) return e;
         raised[backward] = true;
     }
-    const dim3 grid(workgroups(a.M)), block(kThreads);
-    if (backward) TGRU_LAUNCH((head_wide_bwd_kernel<NI, NM, NO>), grid, block, lds, s, a);
-    else TGRU_LAUNCH((head_wide_fwd_kernel<NI, NM, NO>), grid, block, lds, s, a);
+    if (backward)
+        TGRU_LAUNCH((head_wide_bwd_kernel<NI, NM, NO>), dim3(workgroups(a.M)), dim3(kThreads), lds, s, a);
+    else
+        TGRU_LAUNCH((head_wide_fwd_kernel<NI, NM, NO, kFwdWaves>), dim3(workgroups(a.M, kFwdWaves)),
+                    dim3(64 * kFwdWaves), lds, s, a);
     return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ int gemm_split_for(int M, int N, long K, int *kchunk) {
     const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
     long want = 768 / tiles;
     if (want < 1) want = 1;
-    long maxs = K / 512;
+    long maxs = K / 128;
     if (maxs < 1) maxs = 1;
     long ns = want < maxs ? want : maxs;
     long kc = (K + ns - 1) / ns;
