@@ -302,44 +302,76 @@ __global__ __launch_bounds__(64 * NW) void head_wide_fwd_kernel(Args a) {
 // ----------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------
-// column sums of one accumulator set over the 16 rows of every wave of the workgroup -> dst[0..n)
-template <int NT>
-__device__ __forceinline__ void column_sums(float *scratch, int ldr, const float (&v)[4 * NT], int n, float *dst) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    __syncthreads();
-    float *mine = scratch + wave * kRows * ldr;
+// Column sums without an accumulator register per feature.  Lane (g, j) holds, for row j, N values (one per
+// feature slot q); what is wanted is the sum of slot q over the 16 lanes j of the row group.  A butterfly that
+// halves the slots while it doubles the lanes summed (keep one slot of a pair, hand the other to the partner
+// lane) leaves the total of slot q in lane j = q: 16 slots cost 15 adds, 30 selects and 15 lane exchanges,
+// and a whole accumulator set packs into N / 16 registers.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float swz_xor4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }
+__device__ __forceinline__ float swz_xor8(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x201F)); }
+
+struct LaneBits { bool b0, b1, b2, b3; };
+
+// lane j of every 16-lane row gets the sum of v[j] over the row's lanes
+__device__ __forceinline__ float reduce16(const float (&v)[16], const LaneBits &lb) {
+    float t1[8], t2[4], t3[2];
 #pragma unroll
-    for (int ft = 0; ft < NT; ++ft)
-        if (16 * ft < n)
-            *(float4 *)(mine + j * ldr + 16 * ft + 4 * g) = make_float4(v[4 * ft], v[4 * ft + 1], v[4 * ft + 2], v[4 * ft + 3]);
-    __syncthreads();
-    for (int f = threadIdx.x; f < n; f += kThreads) {
-        float s = 0.f;
+    for (int p = 0; p < 8; ++p) t1[p] = (lb.b0 ? v[2 * p + 1] : v[2 * p]) + dpp_xor1(lb.b0 ? v[2 * p] : v[2 * p + 1]);
 #pragma unroll
-        for (int q = 0; q < kWaves * kRows; ++q) s += scratch[q * ldr + f];
-        dst[f] = s;
+    for (int p = 0; p < 4; ++p) t2[p] = (lb.b1 ? t1[2 * p + 1] : t1[2 * p]) + dpp_xor2(lb.b1 ? t1[2 * p] : t1[2 * p + 1]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) t3[p] = (lb.b2 ? t2[2 * p + 1] : t2[2 * p]) + swz_xor4(lb.b2 ? t2[2 * p] : t2[2 * p + 1]);
+    return (lb.b3 ? t3[1] : t3[0]) + swz_xor8(lb.b3 ? t3[0] : t3[1]);
+}
+// P[grp] (lane j) += column total of slot 16*grp + j
+template <int N>
+__device__ __forceinline__ void add_columns(const float (&v)[N], float (&P)[(N + 15) / 16], const LaneBits &lb) {
+#pragma unroll
+    for (int grp = 0; grp < (N + 15) / 16; ++grp) {
+        float t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = (16 * grp + i < N) ? v[16 * grp + i] : 0.f;
+        P[grp] += reduce16(t, lb);
+    }
+}
+// packed totals -> this wave's vector in LDS: slot q = 4*ft + r of lane group g is feature 16*ft + 4*g + r
+template <int N>
+__device__ __forceinline__ void put_columns(float *dst, const float (&P)[(N + 15) / 16], int g, int j) {
+#pragma unroll
+    for (int grp = 0; grp < (N + 15) / 16; ++grp) {
+        const int q = 16 * grp + j;
+        if (q < N) dst[16 * (q >> 2) + 4 * g + (q & 3)] = P[grp];
     }
 }
 
-template <int NI, int NM, int NO>
-__global__ __launch_bounds__(kThreads) void head_wide_bwd_kernel(Args a) {
+// NW waves per workgroup (eight where the registers allow two waves per SIMD)
+template <int NI, int NM, int NO, int NW>
+__global__ __launch_bounds__(64 * NW) void head_wide_bwd_kernel(Args a) {
     extern __shared__ __align__(16) float lds[];
     const bool deep = a.w2 != nullptr;
     const Lds l = lds_layout(a.din, a.dmid, a.dout, deep);
     stage_params(a, l, lds, deep);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const LaneBits lb{(j & 1) != 0, (j & 2) != 0, (j & 4) != 0, (j & 8) != 0};
     const bool vec_mid = (a.dmid & 3) == 0;      // workspace rows of dmid floats start 16-byte aligned then
-    float dc1[4 * NM], dg1[4 * NM], db1[4 * NM], dg0[4 * NI], db0[4 * NI], dc2[4 * NO];
+    constexpr int PM = (4 * NM + 15) / 16, PI = (4 * NI + 15) / 16, PO = (4 * NO + 15) / 16;
+    float pc1[PM], pg1[PM], pb1[PM], pg0[PI], pb0[PI], pc2[PO];     // packed column totals, see add_columns
 #pragma unroll
-    for (int q = 0; q < 4 * NM; ++q) dc1[q] = dg1[q] = db1[q] = 0.f;
+    for (int q = 0; q < PM; ++q) pc1[q] = pg1[q] = pb1[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4 * NI; ++q) dg0[q] = db0[q] = 0.f;
+    for (int q = 0; q < PI; ++q) pg0[q] = pb0[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4 * NO; ++q) dc2[q] = 0.f;
+    for (int q = 0; q < PO; ++q) pc2[q] = 0.f;
 
     const int ntiles = (a.M + kRows - 1) / kRows;
-    for (int tile = blockIdx.x * kWaves + wave; tile < ntiles; tile += gridDim.x * kWaves) {
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
         const long row = (long)tile * kRows + j;
         // ---- forward again, keeping what the backward needs --------------------------------------
         float x1[4 * NI], xh0[4 * NI], rstd0 = 1.f;
@@ -382,18 +414,24 @@ __global__ __launch_bounds__(kThreads) void head_wide_bwd_kernel(Args a) {
             {
                 float dy[4 * NO];
                 load_rows<NO>(a.dy, a.M, a.dout, row, g, a.vec_out, dy);
-#pragma unroll
-                for (int q = 0; q < 4 * NO; ++q) dc2[q] += dy[q];
                 apply_wt<NO, NM>(lds + l.w2, l.ld2, a.dmid, a.dout, lane, dy, da);
+                add_columns<4 * NO>(dy, pc2, lb);
             }
             // ReLU and LayerNorm1
             float s1 = 0.f, s2 = 0.f;
+            {
+                float tg[4 * NM];
+#pragma unroll
+                for (int q = 0; q < 4 * NM; ++q) {
+                    da[q] = (hn[q] * g1[q] + b1[q] > 0.f) ? da[q] : 0.f;
+                    tg[q] = da[q] * hn[q];
+                }
+                add_columns<4 * NM>(da, pb1, lb);
+                add_columns<4 * NM>(tg, pg1, lb);
+            }
 #pragma unroll
             for (int q = 0; q < 4 * NM; ++q) {
-                const float dpre = (hn[q] * g1[q] + b1[q] > 0.f) ? da[q] : 0.f;
-                dg1[q] += dpre * hn[q];
-                db1[q] += dpre;
-                da[q] = dpre * g1[q];
+                da[q] *= g1[q];
                 s1 += da[q];
                 s2 += da[q] * hn[q];
             }
@@ -405,19 +443,23 @@ __global__ __launch_bounds__(kThreads) void head_wide_bwd_kernel(Args a) {
             load_rows<NM>(a.dy, a.M, a.dmid, row, g, a.vec_out, dh);
         }
         // ---- Linear1: dc1, dx1 = W1^T . dh   (dW1 = dh^T . x1 is the caller's product) ----------------
-#pragma unroll
-        for (int q = 0; q < 4 * NM; ++q) dc1[q] += dh[q];
         if (a.dx || a.g0) {
             float dx[4 * NI];
             apply_wt<NM, NI>(lds + l.w1, l.ld1, a.din, a.dmid, lane, dh, dx);
+            add_columns<4 * NM>(dh, pc1, lb);
             if (a.g0) {
                 float g0[4 * NI];
                 lds_vec<NI>(lds + l.g0, a.din, g, g0);
+                {
+                    float tg[4 * NI];
+#pragma unroll
+                    for (int q = 0; q < 4 * NI; ++q) tg[q] = dx[q] * xh0[q];
+                    add_columns<4 * NI>(dx, pb0, lb);
+                    add_columns<4 * NI>(tg, pg0, lb);
+                }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4 * NI; ++q) {
-                    dg0[q] += dx[q] * xh0[q];
-                    db0[q] += dx[q];
                     dx[q] *= g0[q];
                     s1 += dx[q];
                     s2 += dx[q] * xh0[q];
@@ -427,23 +469,39 @@ __global__ __launch_bounds__(kThreads) void head_wide_bwd_kernel(Args a) {
                 for (int q = 0; q < 4 * NI; ++q) dx[q] = live(q, g, a.din) ? rstd0 * (dx[q] - m1 - xh0[q] * m2) : 0.f;
             }
             if (a.dx) store_rows<NI>(a.dx, a.M, a.din, row, g, a.vec_in, dx);
+        } else {
+            add_columns<4 * NM>(dh, pc1, lb);
         }
     }
 
     // ---- this workgroup's partial bias / LayerNorm-parameter gradients ---------------------------------
-    // the weights in LDS are done with: the same memory carries the accumulators, one set at a time
+    // the weights in LDS are done with: the same memory carries one vector of totals per wave
     const VecLayout vl = vec_layout(a.din, a.dmid, a.dout);
     float *slab = a.slabs + (long)blockIdx.x * a.slab_stride;
-    constexpr int NMAX = NI > NM ? (NI > NO ? NI : NO) : (NM > NO ? NM : NO);
-    constexpr int ldr = 16 * NMAX + 4;
-    column_sums<NM>(lds, ldr, dc1, a.dmid, slab + vl.c1);
-    column_sums<NI>(lds, ldr, dg0, a.din, slab + vl.g0);
-    column_sums<NI>(lds, ldr, db0, a.din, slab + vl.b0);
-    column_sums<NM>(lds, ldr, dg1, a.dmid, slab + vl.g1);
-    column_sums<NM>(lds, ldr, db1, a.dmid, slab + vl.b1);
-    if (deep) column_sums<NO>(lds, ldr, dc2, a.dout, slab + vl.c2);
+    constexpr int oc1 = 0, og0 = 16 * NM, ob0 = og0 + 16 * NI, og1 = ob0 + 16 * NI, ob1 = og1 + 16 * NM,
+                  oc2 = ob1 + 16 * NM, kStride = oc2 + 16 * NO;
+    __syncthreads();
+    float *mine = lds + wave * kStride;
+    put_columns<4 * NM>(mine + oc1, pc1, g, j);
+    put_columns<4 * NI>(mine + og0, pg0, g, j);
+    put_columns<4 * NI>(mine + ob0, pb0, g, j);
+    put_columns<4 * NM>(mine + og1, pg1, g, j);
+    put_columns<4 * NM>(mine + ob1, pb1, g, j);
+    put_columns<4 * NO>(mine + oc2, pc2, g, j);
+    __syncthreads();
+    const int src[6] = {oc1, og0, ob0, og1, ob1, oc2};
+    const int dst[6] = {vl.c1, vl.g0, vl.b0, vl.g1, vl.b1, vl.c2};
+    const int len[6] = {a.dmid, a.din, a.din, a.dmid, a.dmid, deep ? a.dout : 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        for (int f = threadIdx.x; f < len[k]; f += blockDim.x) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += lds[w * kStride + src[k] + f];
+            slab[dst[k] + f] = sum;
+        }
     if (a.zero && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < a.nzero; i += kThreads) a.zero[i] = 0.f;
+        for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero[i] = 0.f;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -451,19 +509,21 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int NI, int NM, int NO>
 size_t lds_bytes(int din, int dmid, int dout, bool deep, bool backward) {
     size_t b = (size_t)lds_layout(din, dmid, dout, deep).total * sizeof(float);
-    if (backward) {
-        constexpr int NMAX = NI > NM ? (NI > NO ? NI : NO) : (NM > NO ? NM : NO);
-        const size_t r = (size_t)kWaves * kRows * (16 * NMAX + 4) * sizeof(float);
+    if (backward) {      // one vector of column totals per wave, in the weights' place
+        const size_t r = (size_t)8 * 16 * (3 * NM + 2 * NI + NO) * sizeof(float);
         if (r > b) b = r;
     }
     return b;
 }
 
 constexpr int kFwdWaves = 8;
-int workgroups(int M, int waves = kWaves) {
+int workgroups(int M, int waves) {
     const int groups = ((M + kRows - 1) / kRows + waves - 1) / waves;
     return groups < 256 ? groups : 256;
 }
+// waves per workgroup of the backward kernel: two per SIMD where its registers allow (every width <= 96)
+int bwd_waves(int din, int dmid, int dout) { return (din <= 96 && dmid <= 96 && dout <= 96) ? 8 : kWaves; }
+int bwd_workgroups(int M, int din, int dmid, int dout) { return workgroups(M, bwd_waves(din, dmid, dout)); }
 
 // workspace (floats): partial vectors | LayerNorm0 output | ReLU output | gradient at the Linear1 output |
 // split-K partials of dW1 | of dW2.  Sized without knowing which stages a call has.
@@ -472,7 +532,7 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 Ws ws_layout(int M, int din, int dmid, int dout) {
     Ws w;
     size_t o = 0;
-    w.slabs = o; o += align64((size_t)workgroups(M) * vec_layout(din, dmid, dout).total);
+    w.slabs = o; o += align64((size_t)bwd_workgroups(M, din, dmid, dout) * vec_layout(din, dmid, dout).total);
     w.xn = o; o += align64((size_t)M * din);
     w.act = o; o += align64((size_t)M * dmid);
     w.dh = o; o += align64((size_t)M * dmid);
@@ -484,11 +544,11 @@ Ws ws_layout(int M, int din, int dmid, int dout) {
     return w;
 }
 
-template <int NI, int NM, int NO>
+template <int NI, int NM, int NO, int NWB>
 hipError_t launch(const Args &a, bool backward, hipStream_t s) {
     const bool deep = a.w2 != nullptr;
     const size_t lds = lds_bytes<NI, NM, NO>(a.din, a.dmid, a.dout, deep, backward);
-    const void *fn = backward ? reinterpret_cast<const void *>(head_wide_bwd_kernel<NI, NM, NO>)
+    const void *fn = backward ? reinterpret_cast<const void *>(head_wide_bwd_kernel<NI, NM, NO, NWB>)
                               : reinterpret_cast<const void *>(head_wide_fwd_kernel<NI, NM, NO, kFwdWaves>);
     static bool raised[2] = {false, false};       // per template instance and direction
     if (!raised[backward]) {
@@ -497,7 +557,7 @@ hipError_t launch(const Args &a, bool backward, hipStream_t s) {
         raised[backward] = true;
     }
     if (backward)
-        TGRU_LAUNCH((head_wide_bwd_kernel<NI, NM, NO>), dim3(workgroups(a.M)), dim3(kThreads), lds, s, a);
+        TGRU_LAUNCH((head_wide_bwd_kernel<NI, NM, NO, NWB>), dim3(workgroups(a.M, NWB)), dim3(64 * NWB), lds, s, a);
     else
         TGRU_LAUNCH((head_wide_fwd_kernel<NI, NM, NO, kFwdWaves>), dim3(workgroups(a.M, kFwdWaves)),
                     dim3(64 * kFwdWaves), lds, s, a);
@@ -505,9 +565,9 @@ hipError_t launch(const Args &a, bool backward, hipStream_t s) {
 }
 
 hipError_t dispatch(const Args &a, bool backward, hipStream_t s) {
-    if (a.din <= 96 && a.dmid <= 96 && a.dout <= 96) return launch<6, 6, 6>(a, backward, s);
-    if (a.din <= 32 && a.dout <= 96) return launch<2, 12, 6>(a, backward, s);
-    return launch<8, 12, 8>(a, backward, s);
+    if (a.din <= 96 && a.dmid <= 96 && a.dout <= 96) return launch<6, 6, 6, 8>(a, backward, s);   // see bwd_waves
+    if (a.din <= 32 && a.dout <= 96) return launch<2, 12, 6, kWaves>(a, backward, s);
+    return launch<8, 12, 8, kWaves>(a, backward, s);
 }
 
 void fill(const tgru_head_args &c, bool backward, Args &a) {
@@ -541,10 +601,10 @@ int reduce_jobs(const tgru_head_args &c, tgru_reduce_job *jobs) {
     float *d = c.dparams;
     int n = 0;
     jobs[n++] = tgru_reduce_job{c.workspace + w.p1, (int64_t)n1, w.ns1, n1, d};
-    jobs[n++] = tgru_reduce_job{c.workspace + w.slabs, (int64_t)vl.total, workgroups(c.M), nvec, d + n1};
+    jobs[n++] = tgru_reduce_job{c.workspace + w.slabs, (int64_t)vl.total, bwd_workgroups(c.M, c.din, c.dmid, c.dout), nvec, d + n1};
     if (!deep) return n;        // no Linear2: the backward kernel has written zeros there
     jobs[n++] = tgru_reduce_job{c.workspace + w.p2, (int64_t)n2, w.ns2, n2, d + n1 + nvec};
-    jobs[n++] = tgru_reduce_job{c.workspace + w.slabs + vl.c2, (int64_t)vl.total, workgroups(c.M), c.dout,
+    jobs[n++] = tgru_reduce_job{c.workspace + w.slabs + vl.c2, (int64_t)vl.total, bwd_workgroups(c.M, c.din, c.dmid, c.dout), c.dout,
                                 d + n1 + nvec + n2};
     return n;
 }
