@@ -242,7 +242,8 @@ int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b,
  *      dW1 (dmid*din) | db1 (dmid) | dln0_w (din) | dln0_b (din) | dln1_w (dmid) | dln1_b (dmid) |
  *      dW2 (dout*dmid) | db2 (dout)
  * (entries of absent stages are written as zeros unless accumulate == 1).  `workspace` needs
- * tgru_head_backward_workspace_bytes() bytes.  accumulate != 0 adds to dparams.
+ * tgru_head_backward_workspace_bytes() bytes (16-byte aligned for the LDS-resident widths: TGRU_E_ALIGN
+ * otherwise).  accumulate != 0 adds to dparams.
  */
 int tgru_head_supported(int din, int dmid, int dout, int deep);   /* deep: Linear2 present */
 size_t tgru_head_grad_floats(int din, int dmid, int dout);

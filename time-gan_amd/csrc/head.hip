@@ -543,6 +543,7 @@ int head_check(const tgru_head_args &c, bool backward) {
     if ((c.ln0_w && !c.ln0_b) || (c.w2 && (!c.ln1_w || !c.ln1_b || !c.b2))) return TGRU_E_NULL;
     if (backward ? (!c.dy || !c.dparams || !c.workspace) : !c.y) return TGRU_E_NULL;
     if (!head::aligned16(c.w1) || (c.w2 && !head::aligned16(c.w2))) return TGRU_E_ALIGN;
+    if (backward && is_wide(c) && !head::aligned16(c.workspace)) return TGRU_E_ALIGN;   // rows moved as float4
     return TGRU_OK;
 }
 

@@ -550,11 +550,14 @@ hipError_t launch(const Args &a, bool backward, hipStream_t s) {
     const size_t lds = lds_bytes<NI, NM, NO>(a.din, a.dmid, a.dout, deep, backward);
     const void *fn = backward ? reinterpret_cast<const void *>(head_wide_bwd_kernel<NI, NM, NO, NWB>)
                               : reinterpret_cast<const void *>(head_wide_fwd_kernel<NI, NM, NO, kFwdWaves>);
-    static bool raised[2] = {false, false};       // per template instance and direction
-    if (!raised[backward]) {
+    // the LDS limit is raised once per device, template instance and direction
+    static std::atomic<unsigned long long> raised[2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!(raised[backward].load(std::memory_order_relaxed) >> dev & 1ULL)) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
         if (e != hipSuccess) return e;
-        raised[backward] = true;
+        raised[backward].fetch_or(1ULL << dev, std::memory_order_relaxed);
     }
     if (backward)
         TGRU_LAUNCH((head_wide_bwd_kernel<NI, NM, NO, NWB>), dim3(workgroups(a.M, NWB)), dim3(64 * NWB), lds, s, a);
