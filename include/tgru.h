@@ -311,7 +311,7 @@ int tgru_reduce_jobs(const tgru_reduce_job *jobs, int n_jobs, tgru_stream_t stre
  * Replaces torch's _foreach_add_ + _fused_adam_ launches.
  */
 #define TGRU_MAX_ADAM_JOBS 64
-#define TGRU_MAX_ADAM_ELEMS 16384
+#define TGRU_MAX_ADAM_ELEMS 65536
 typedef struct tgru_adam_job {
     float *param;
     const float *grad;

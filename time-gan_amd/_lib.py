@@ -55,7 +55,7 @@ class AdamJob(ctypes.Structure):
 
 
 MAX_ADAM_JOBS = 64        # TGRU_MAX_ADAM_JOBS
-MAX_ADAM_ELEMS = 16384    # TGRU_MAX_ADAM_ELEMS
+MAX_ADAM_ELEMS = 65536    # TGRU_MAX_ADAM_ELEMS
 DEFER_REDUCE = 2          # TGRU_DEFER_REDUCE
 STATIC_WORKSPACE_BYTES = 64 << 20   # TGRU_STATIC_WORKSPACE_BYTES
 MAX_JOBS_PER_CALL = 32    # upper bound of jobs one backward call can owe (5 per layer, at most 4 layers on that path)

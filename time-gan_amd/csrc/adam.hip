@@ -19,7 +19,7 @@ namespace tgru {
 namespace adam {
 
 constexpr int kMaxJobs = TGRU_MAX_ADAM_JOBS;
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;     // the largest tensors (64 K elements) are sixteen float4 rounds of one workgroup
 
 struct Table {
     tgru_adam_job job[kMaxJobs];
@@ -40,7 +40,30 @@ __global__ __launch_bounds__(kThreads) void adam_jobs_kernel(Table t) {
     const int n = j.n;
     float *p = j.param, *ma = j.exp_avg, *va = j.exp_avg_sq;
     const float *ga = j.grad;
-    for (int idx = threadIdx.x; idx < n; idx += kThreads) {
+    // whole float4s where all four arrays are 16-byte aligned (gradients may be views into a flat buffer)
+    int done = 0;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ma) | reinterpret_cast<uintptr_t>(va) |
+          reinterpret_cast<uintptr_t>(ga)) & 15) == 0) {
+        const float omb1 = 1.f - t.beta1, omb2 = 1.f - t.beta2;
+        for (int i4 = threadIdx.x; i4 < (n >> 2); i4 += kThreads) {
+            const float4 g4 = reinterpret_cast<const float4 *>(ga)[i4];
+            float4 m4 = reinterpret_cast<float4 *>(ma)[i4], v4 = reinterpret_cast<float4 *>(va)[i4];
+            float4 p4 = reinterpret_cast<float4 *>(p)[i4];
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, w[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[e] = m[e] + omb1 * (g[e] - m[e]);
+                v[e] = t.beta2 * v[e] + omb2 * g[e] * g[e];
+                w[e] -= step_size * m[e] / (sqrtf(v[e]) / bc2s + t.eps);
+            }
+            reinterpret_cast<float4 *>(p)[i4] = make_float4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<float4 *>(ma)[i4] = make_float4(m[0], m[1], m[2], m[3]);
+            reinterpret_cast<float4 *>(va)[i4] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        done = n & ~3;
+    }
+    for (int idx = done + threadIdx.x; idx < n; idx += kThreads) {
         const float g = ga[idx];
         float m = ma[idx], v = va[idx];
         m = m + (1.f - t.beta1) * (g - m);

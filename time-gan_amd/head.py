@@ -86,8 +86,8 @@ def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear], lns=(
     """True when the fused kernels cover this head: GPU fp32 rows, widths the library takes
     (tgru_head_supported: input / output up to 128, the middle between the two Linears up to 192), biases
     present."""
-    if not x.is_cuda or x.dtype != torch.float32:
-        return False
+    if not x.is_cuda or x.dtype != torch.float32 or x.numel() == 0:
+        return False      # (an empty shard keeps the torch modules, which return an empty result)
     if lin1.bias is None or (lin2 is not None and lin2.bias is None):
         return False
     if any(ln is not None and (ln.weight is None or ln.bias is None) for ln in lns):
