@@ -52,6 +52,7 @@ __host__ __device__ inline Layout layout_of(int C) {
 
 struct Args {
     int kind, pass, B, T, H, C;
+    int small;               // every element index fits in 31 bits: 32-bit index arithmetic
     int type[3];
     const float *a[3];
     const float *b[3];
@@ -69,15 +70,18 @@ __device__ __forceinline__ float softplus_neg(float y) {   // -log_sigmoid(y) = 
     return log1pf(expf(-fabsf(y))) - fminf(y, 0.f);
 }
 
-__device__ __forceinline__ float term_value(int type, const float *a, const float *b, long e, int T, int H) {
+// I: the index type -- 32-bit wherever the tensors allow (a 64-bit division per element costs more than
+// everything else these kernels do)
+template <typename I>
+__device__ __forceinline__ float term_value(int type, const float *a, const float *b, I e, int T, int H) {
     if (type == kSq) {
         const float d = a[e] - b[e];
         return d * d;
     }
     if (type == kSqShift) {
-        const long th1 = (long)(T - 1) * H;
-        const long bb = e / th1;
-        const long ia = bb * T * H + (e - bb * th1);
+        const I th1 = (I)(T - 1) * (I)H;
+        const I bb = e / th1;
+        const I ia = bb * (I)T * (I)H + (e - bb * th1);
         const float d = a[ia] - b[ia + H];
         return d * d;
     }
@@ -107,9 +111,16 @@ __global__ __launch_bounds__(kThreads) void loss_partial_kernel(Args p) {
     if ((int)blockIdx.x < nterm_blocks) {
         const int k = blockIdx.x / kSlots, j = blockIdx.x % kSlots;
         float s = 0.f;
-        if (p.type[k] != kNone)
-            for (long e = (long)j * kThreads + tid; e < p.n[k]; e += (long)kSlots * kThreads)
-                s += term_value(p.type[k], p.a[k], p.b[k], e, p.T, p.H);
+        if (p.type[k] != kNone) {
+            if (p.small) {
+                const unsigned n = (unsigned)p.n[k];
+                for (unsigned e = (unsigned)j * kThreads + tid; e < n; e += kSlots * kThreads)
+                    s += term_value<unsigned>(p.type[k], p.a[k], p.b[k], e, p.T, p.H);
+            } else {
+                for (long e = (long)j * kThreads + tid; e < p.n[k]; e += (long)kSlots * kThreads)
+                    s += term_value<long>(p.type[k], p.a[k], p.b[k], e, p.T, p.H);
+            }
+        }
         s = block_sum(s, red);
         if (tid == 0) p.buf[l.partial + blockIdx.x] = s;
         if (blockIdx.x == 0 && tid < 4)
@@ -124,11 +135,21 @@ __global__ __launch_bounds__(kThreads) void loss_partial_kernel(Args p) {
     float mh, mx;
     if (p.pass != 2) {
         float sh = 0.f, sx = 0.f;
-        if (ok)
-            for (int r = rl; r < p.B; r += 16) {
-                sh += p.xh[(long)r * p.C + col];
-                sx += p.x[(long)r * p.C + col];
+        if (ok) {      // four rows per round: eight loads in flight, fixed association
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+            int r = rl;
+            for (; r + 48 < p.B; r += 64) {
+                const long o = (long)r * p.C + col, d = 16L * p.C;
+                h0 += p.xh[o]; h1 += p.xh[o + d]; h2 += p.xh[o + 2 * d]; h3 += p.xh[o + 3 * d];
+                x0 += p.x[o]; x1 += p.x[o + d]; x2 += p.x[o + 2 * d]; x3 += p.x[o + 3 * d];
             }
+            for (; r < p.B; r += 16) {
+                h0 += p.xh[(long)r * p.C + col];
+                x0 += p.x[(long)r * p.C + col];
+            }
+            sh = (h0 + h1) + (h2 + h3);
+            sx = (x0 + x1) + (x2 + x3);
+        }
         cred[0][rl][cl] = sh;
         cred[1][rl][cl] = sx;
         __syncthreads();
@@ -151,13 +172,25 @@ __global__ __launch_bounds__(kThreads) void loss_partial_kernel(Args p) {
         mx = ok ? p.buf[l.colsum + p.C + col] / nb : 0.f;
     }
     float qh = 0.f, qx = 0.f;
-    if (ok)
-        for (int r = rl; r < p.B; r += 16) {
+    if (ok) {
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        int r = rl;
+        for (; r + 48 < p.B; r += 64) {
+            const long o = (long)r * p.C + col, d = 16L * p.C;
+            const float a0 = p.xh[o] - mh, a1 = p.xh[o + d] - mh, a2 = p.xh[o + 2 * d] - mh, a3 = p.xh[o + 3 * d] - mh;
+            const float b0 = p.x[o] - mx, b1 = p.x[o + d] - mx, b2 = p.x[o + 2 * d] - mx, b3 = p.x[o + 3 * d] - mx;
+            h0 += a0 * a0; h1 += a1 * a1; h2 += a2 * a2; h3 += a3 * a3;
+            x0 += b0 * b0; x1 += b1 * b1; x2 += b2 * b2; x3 += b3 * b3;
+        }
+        for (; r < p.B; r += 16) {
             const float dh = p.xh[(long)r * p.C + col] - mh;
             const float dx = p.x[(long)r * p.C + col] - mx;
-            qh += dh * dh;
-            qx += dx * dx;
+            h0 += dh * dh;
+            x0 += dx * dx;
         }
+        qh = (h0 + h1) + (h2 + h3);
+        qx = (x0 + x1) + (x2 + x3);
+    }
     cred[0][rl][cl] = qh;
     cred[1][rl][cl] = qx;
     __syncthreads();
@@ -259,10 +292,12 @@ __global__ __launch_bounds__(kThreads) void loss_backward_kernel(Args p) {
         const int type = p.type[k];
         if (type == kNone || (!p.da[k] && !p.db[k])) return;
         const float c = term_coef(p, l, k);
-        const float *a = p.a[k], *b = p.b[k];
-        float *da = p.da[k], *db = p.db[k];
+        // no output aliases an input: loads of later elements may pass the stores of earlier ones
+        const float *__restrict__ a = p.a[k], *__restrict__ b = p.b[k];
+        float *__restrict__ da = p.da[k], *__restrict__ db = p.db[k];
         const long stride = (long)kSlots * kThreads;
         if (type == kSq) {
+#pragma unroll 4
             for (long e = (long)j * kThreads + tid; e < p.n[k]; e += stride) {
                 const float v = 2.f * c * (a[e] - b[e]);
                 if (da) da[e] = v;
@@ -270,10 +305,20 @@ __global__ __launch_bounds__(kThreads) void loss_backward_kernel(Args p) {
             }
         } else if (type == kSqShift) {
             const long n = (long)p.B * p.T * p.H;
-            for (long e = (long)j * kThreads + tid; e < n; e += stride) {
-                const int t = (int)((e / p.H) % p.T);
-                if (da) da[e] = t < p.T - 1 ? 2.f * c * (a[e] - b[e + p.H]) : 0.f;
-                if (db) db[e] = t >= 1 ? -2.f * c * (a[e - p.H] - b[e]) : 0.f;
+            if (p.small) {
+                const unsigned H = p.H, T = p.T;
+#pragma unroll 4
+                for (unsigned e = (unsigned)j * kThreads + tid; e < (unsigned)n; e += (unsigned)stride) {
+                    const unsigned t = (e / H) % T;
+                    if (da) da[e] = t < T - 1 ? 2.f * c * (a[e] - b[e + H]) : 0.f;
+                    if (db) db[e] = t >= 1 ? -2.f * c * (a[e - H] - b[e]) : 0.f;
+                }
+            } else {
+                for (long e = (long)j * kThreads + tid; e < n; e += stride) {
+                    const int t = (int)((e / p.H) % p.T);
+                    if (da) da[e] = t < p.T - 1 ? 2.f * c * (a[e] - b[e + p.H]) : 0.f;
+                    if (db) db[e] = t >= 1 ? -2.f * c * (a[e - p.H] - b[e]) : 0.f;
+                }
             }
         } else if (da) {
             const float tgt = type == kBceOne ? 1.f : 0.f;
@@ -289,6 +334,13 @@ __global__ __launch_bounds__(kThreads) void loss_backward_kernel(Args p) {
     const float cm = g0 * 1000.f / (float)p.C / nb;
     const long n = (long)p.B * p.C;
     const int nmb = gridDim.x - 3 * kSlots;
+    if (p.small) {
+        for (unsigned e = (blockIdx.x - 3 * kSlots) * kThreads + tid; e < (unsigned)n; e += (unsigned)nmb * kThreads) {
+            const float4 st = *(const float4 *)(p.buf + l.colstat + 4L * (e % (unsigned)p.C));
+            p.dxh[e] = cm * (st.w + st.z * (p.xh[e] - st.x) / st.y);
+        }
+        return;
+    }
     for (long e = (long)(blockIdx.x - 3 * kSlots) * kThreads + tid; e < n; e += (long)nmb * kThreads) {
         const float4 st = *(const float4 *)(p.buf + l.colstat + 4L * (e % p.C));
         p.dxh[e] = cm * (st.w + st.z * (p.xh[e] - st.x) / st.y);
@@ -299,6 +351,7 @@ static int fill_args(Args &a, int kind, const float *const *in, float *const *di
     if (B <= 0 || T <= 0 || H <= 0 || F <= 0) return TGRU_E_DIMS;
     if ((long long)B * T * (H > F ? H : F) >= (1LL << 40)) return TGRU_E_DIMS;
     a.kind = kind; a.B = B; a.T = T; a.H = H; a.C = 0;
+    a.small = (long long)B * T * (H > F ? H : F) < (1LL << 30);     // with room for the grid-stride increment
     const long nx = (long)B * T * F, nshift = (long)B * (T - 1) * H, ny = (long)B * T;
     int need = 0;
     auto term = [&](int k, int type, int ia, int ib, long n) {
