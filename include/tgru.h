@@ -140,7 +140,9 @@ int tgru_forward_static(const float *x, const float *h0,
  *   dx       (rows, In) in `layout`, or NULL when the input needs no gradient
  *   dh0      (L, B, H), or NULL
  *   dw_ih / dw_hh / db_ih / db_hh: host arrays of L device pointers; every buffer is
- *            overwritten (accumulate == 0) or added to (accumulate != 0)
+ *            overwritten (accumulate == 0) or added to (accumulate != 0).  All four arrays NULL: no
+ *            weight / bias gradients are formed, only dx / dh0 (a network the step does not update, whose
+ *            gradients the reference zeroes unseen: outdated_files/TimeGANv1.py:765-769,780-782,796-799)
  *   workspace tgru_backward_workspace_bytes() bytes
  */
 int tgru_backward(const float *dy, const float *dh_n,
@@ -241,7 +243,8 @@ int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b,
  * gradients into ONE flat buffer `dparams` of tgru_head_grad_floats() floats laid out as
  *      dW1 (dmid*din) | db1 (dmid) | dln0_w (din) | dln0_b (din) | dln1_w (dmid) | dln1_b (dmid) |
  *      dW2 (dout*dmid) | db2 (dout)
- * (entries of absent stages are written as zeros unless accumulate == 1).  `workspace` needs
+ * (entries of absent stages are written as zeros unless accumulate == 1; dparams NULL: no parameter
+ * gradients are formed, only dx -- for a network whose parameters the step does not update).  `workspace` needs
  * tgru_head_backward_workspace_bytes() bytes (16-byte aligned for the LDS-resident widths: TGRU_E_ALIGN
  * otherwise).  accumulate != 0 adds to dparams.
  */

@@ -220,3 +220,34 @@ def test_head_pair_equals_separate_calls(pair):
     ref, got = run(False), run(True)
     for i, (u, v) in enumerate(zip(got, ref)):
         assert torch.equal(u, v), f"tensor {i}: max diff {float((u - v).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("case", [(3072, 24, 24, 6, True, True), (3072, 6, 48, 24, False, True), (3072, 24, 24, 24, True, False),
+                                  (4096, 96, 96, 28, True, True), (4096, 28, 192, 96, False, True),
+                                  (4096, 96, 96, 96, True, False)], ids=lambda c: "m%d_%d_%d_%d_ln%d_deep%d" % c)
+def test_frozen_head_gives_the_same_input_gradient(case):
+    """A head whose parameters want no gradient: dparams NULL, no reduction / weight-gradient products, dx bit
+    for bit that of the full backward pass."""
+    import timegan_amd as tg
+    from timegan_amd.head import head_apply
+    M, din, dmid, dout, ln0, deep = case
+    m = {k: (None if v is None else v.to("cuda:0")) for k, v in _modules(din, dmid, dout, ln0, deep, seed=11).items()}
+    params = [p for v in m.values() if v is not None for p in v.parameters()]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, din, generator=g).cuda()
+    dy = torch.randn(M, dout, generator=g).cuda()
+
+    def run(frozen):
+        for p in params:
+            p.grad = None
+            p.requires_grad_(not frozen)
+        xi = x.clone().requires_grad_(True)
+        before = tg.lib().tgru_launch_count()
+        (head_apply(xi, m["ln0"], m["lin1"], m["ln1"], m["lin2"]) * dy).sum().backward()
+        return xi.grad, tg.lib().tgru_launch_count() - before
+
+    full, n_full = run(False)
+    part, n_part = run(True)
+    assert all(p.grad is None for p in params)
+    assert torch.equal(part, full)
+    assert n_part < n_full

@@ -297,3 +297,46 @@ def test_batched_products_with_and_without_the_loader_wave(B, T, In, H, L, time_
     finally:
         monkeypatch.delenv("TGRU_GEMM_NO_DMA", raising=False)
         tg.reload_switches()
+
+
+@pytest.mark.parametrize("B,T,In,H,L", [(8, 6, 5, 12, 2),        # one sequence per workgroup
+                                        (40, 6, 30, 30, 2),      # (packed below) MFMA whole-stack kernels
+                                        (16, 6, 28, 96, 2),      # four-sequence kernels, dX inside at the upper layer
+                                        (20, 8, 28, 40, 2),      # four-sequence kernels + row-split weight gradients
+                                        (130, 4, 64, 160, 1)])   # per-tile kernels of the large hidden sizes
+def test_frozen_weights_give_the_same_input_gradient(B, T, In, H, L):
+    """A stack whose parameters want no gradient (a network the training step does not update): the library
+    is handed NULL gradient arrays and launches no weight-gradient stage; dx and dh0 are bit for bit those of
+    the full backward pass, and the parameters receive nothing."""
+    import timegan_amd as tg
+    torch.manual_seed(B + H)
+    rnn = tg.GRU(In, H, num_layers=L, batch_first=True).to("cuda:0")
+    x = torch.randn(B, T, In, device="cuda:0")
+    h0 = torch.randn(L, B, H, device="cuda:0")
+    dy = torch.randn(B, T, H, device="cuda:0")
+    lengths = [T] * B if B != 40 else sorted(np.random.RandomState(0).randint(1, T + 1, B).tolist(), reverse=True)
+
+    def run(frozen):
+        for p in rnn.parameters():
+            p.grad = None
+            p.requires_grad_(not frozen)
+        xi, hi = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        y, h_n = rnn(xi, hi, lengths=lengths)
+        ((y * dy).sum() + h_n.sum()).backward()
+        return xi.grad, hi.grad
+
+    try:
+        full = run(False)
+        assert all(p.grad is not None for p in rnn.parameters())
+        before = tg.lib().tgru_launch_count()
+        part = run(True)
+        launches_frozen = tg.lib().tgru_launch_count() - before
+        before = tg.lib().tgru_launch_count()
+        run(False)
+        launches_full = tg.lib().tgru_launch_count() - before
+    finally:
+        for p in rnn.parameters():
+            p.requires_grad_(True)
+    assert all(p.grad is not None for p in rnn.parameters())      # from the last full run only
+    assert torch.equal(part[0], full[0]) and torch.equal(part[1], full[1])
+    assert launches_frozen < launches_full

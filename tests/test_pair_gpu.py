@@ -53,3 +53,34 @@ def test_pair_equals_separate_calls(case):
     got = _run(True, rnn_a, x_a, len_a, rnn_b, x_b, len_b)
     for i, (u, v) in enumerate(zip(got, ref)):
         assert torch.equal(u, v), f"tensor {i}: max diff {float((u - v).abs().max()):.3e}"
+
+
+def test_pair_with_a_frozen_network_fed_by_data():
+    """The embedder / generator pair of a generator sub-step: the embedder is not updated and its input is
+    data, so it owes nothing in the backward pass; the generator's gradients are those of the full pair."""
+    import timegan_amd as tg
+    from timegan_amd.modules import forward_pair
+    cfg = tg.make_cfg(features=5, hidden=12, layers=2, seq_len=8, device="cuda:0")
+    torch.manual_seed(3)
+    nets = {k: v.to("cuda:0") for k, v in tg.build_networks(cfg).items()}
+    x = torch.rand(16, 8, 5, device="cuda:0")
+    z = torch.rand(16, 8, 5, device="cuda:0")
+    t = [8] * 16
+
+    def run(frozen):
+        for k in ("emb", "g"):
+            for p in nets[k].parameters():
+                p.grad = None
+                p.requires_grad_(not (frozen and k == "emb"))
+        h, e_hat = forward_pair(nets["emb"], x, t, nets["g"], z, t)
+        ((h * h).mean() + (e_hat * e_hat).mean() * 2 + (h * e_hat).mean()).backward()
+        return [p.grad.clone() for p in nets["g"].parameters()]
+
+    try:
+        full, part = run(False), run(True)
+        assert all(p.grad is None for p in nets["emb"].parameters())
+    finally:
+        for p in nets["emb"].parameters():
+            p.requires_grad_(True)
+    for u, v in zip(part, full):
+        assert torch.equal(u, v)

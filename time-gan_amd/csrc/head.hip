@@ -541,7 +541,7 @@ int head_check(const tgru_head_args &c, bool backward) {
     if ((long long)c.M * 64 >= (1LL << 31)) return TGRU_E_DIMS;
     if (!c.w1 || !c.b1 || !c.x) return TGRU_E_NULL;
     if ((c.ln0_w && !c.ln0_b) || (c.w2 && (!c.ln1_w || !c.ln1_b || !c.b2))) return TGRU_E_NULL;
-    if (backward ? (!c.dy || !c.dparams || !c.workspace) : !c.y) return TGRU_E_NULL;
+    if (backward ? (!c.dy || !c.workspace) : !c.y) return TGRU_E_NULL;     // dparams NULL: dx only
     if (!head::aligned16(c.w1) || (c.w2 && !head::aligned16(c.w2))) return TGRU_E_ALIGN;
     if (backward && is_wide(c) && !head::aligned16(c.workspace)) return TGRU_E_ALIGN;   // rows moved as float4
     return TGRU_OK;
@@ -641,8 +641,8 @@ int head_backward_impl(const tgru_head_args *a, const tgru_head_args *b, hipStre
     // reductions that are not deferred to a later tgru_reduce_jobs launch
     const tgru_head_args *now[2] = {nullptr, nullptr};
     int n = 0;
-    if (a->accumulate != TGRU_DEFER_REDUCE) now[n++] = a;
-    if (b && b->accumulate != TGRU_DEFER_REDUCE) now[n++] = b;
+    if (a->accumulate != TGRU_DEFER_REDUCE && a->dparams) now[n++] = a;
+    if (b && b->accumulate != TGRU_DEFER_REDUCE && b->dparams) now[n++] = b;
     if (n == 0) return TGRU_OK;
     return head_reduce_launch(*now[0], now[1], s) == hipSuccess ? TGRU_OK : TGRU_E_LAUNCH;
 }
@@ -692,7 +692,7 @@ int tgru_head_reduce_jobs(const tgru_head_args *c, tgru_reduce_job *jobs, int ma
     if (!c || !jobs) return TGRU_E_NULL;
     const int rc = head_check(*c, true);
     if (rc != TGRU_OK) return rc;
-    if (c->accumulate != TGRU_DEFER_REDUCE) return 0;
+    if (c->accumulate != TGRU_DEFER_REDUCE || !c->dparams) return 0;
     if (is_wide(*c)) return head_wide_reduce_jobs(*c, jobs, max_jobs);
     if (max_jobs < 1) return TGRU_E_DIMS;
     const int total = head::grad_layout(c->din, c->dmid, c->dout).total;

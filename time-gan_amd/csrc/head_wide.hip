@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * NW) void head_wide_bwd_kernel(Args a) {
                 xh0[q] = live(q, g, a.din) ? (x1[q] - mean) * rstd0 : 0.f;
                 x1[q] = xh0[q] * g0[q] + b0[q];
             }
-            store_rows<NI>(a.xn, a.M, a.din, row, g, (a.din & 3) == 0, x1);
+            if (a.xn) store_rows<NI>(a.xn, a.M, a.din, row, g, (a.din & 3) == 0, x1);
         }
         float dh[4 * NM];             // gradient at the output of Linear1
         if (deep) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void head_wide_bwd_kernel(Args a) {
                 float act[4 * NM];
 #pragma unroll
                 for (int q = 0; q < 4 * NM; ++q) act[q] = fmaxf(hn[q] * g1[q] + b1[q], 0.f);
-                store_rows<NM>(a.act, a.M, a.dmid, row, g, vec_mid, act);
+                if (a.act) store_rows<NM>(a.act, a.M, a.dmid, row, g, vec_mid, act);
             }
             // Linear2: dc2, da = W2^T . dy   (dW2 = dy^T . act is the caller's product)
             float da[4 * NM];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void head_wide_bwd_kernel(Args a) {
             const float m1 = row_sum(s1) / (float)a.dmid, m2 = row_sum(s2) / (float)a.dmid;
 #pragma unroll
             for (int q = 0; q < 4 * NM; ++q) dh[q] = live(q, g, a.dmid) ? rstd1 * (da[q] - m1 - hn[q] * m2) : 0.f;
-            store_rows<NM>(a.dh, a.M, a.dmid, row, g, vec_mid, dh);
+            if (a.dh) store_rows<NM>(a.dh, a.M, a.dmid, row, g, vec_mid, dh);
         } else {
             load_rows<NM>(a.dy, a.M, a.dmid, row, g, a.vec_out, dh);
         }
@@ -582,8 +582,10 @@ void fill(const tgru_head_args &c, bool backward, Args &a) {
         a.vec_out = (c.dout % 4 == 0) && aligned16(c.dy);
         const Ws w = ws_layout(c.M, c.din, c.dmid, c.dout);
         a.slabs = c.workspace + w.slabs; a.slab_stride = vec_layout(c.din, c.dmid, c.dout).total;
-        a.xn = c.workspace + w.xn; a.act = c.workspace + w.act; a.dh = c.workspace + w.dh;
-        if (!c.w2 && c.accumulate != 1) {      // dW2 | db2 of a head without Linear2 read as zeros
+        if (c.dparams) {     // operands of the weight-gradient products (no parameter gradients wanted: not written)
+            a.xn = c.workspace + w.xn; a.act = c.workspace + w.act; a.dh = c.workspace + w.dh;
+        }
+        if (c.dparams && !c.w2 && c.accumulate != 1) {      // dW2 | db2 of a head without Linear2 read as zeros
             a.zero = c.dparams + c.dmid * c.din + vec_layout(c.din, c.dmid, c.dout).c2;
             a.nzero = c.dout * c.dmid + c.dout;
         }
@@ -637,6 +639,7 @@ int head_wide_backward(const tgru_head_args &c, hipStream_t s) {
     headw::fill(c, true, a);
     const bool deep = c.w2 != nullptr;
     if (headw::dispatch(a, true, s) != hipSuccess) return TGRU_E_LAUNCH;
+    if (!c.dparams) return TGRU_OK;          // dx only
     const headw::Ws w = headw::ws_layout(c.M, c.din, c.dmid, c.dout);
     // dW1 (dmid x din) = dh^T . (Linear1 input), dW2 (dout x dmid) = dy^T . (ReLU output): split over the rows
     GemmArgs g{};

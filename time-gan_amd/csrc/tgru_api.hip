@@ -460,15 +460,17 @@ int tgru_forward_pair(const tgru_forward_args *a, const tgru_forward_args *b, tg
 static int check_backward(const tgru_backward_args &c) {
     int rc = check_dims(c.B, c.T, c.In, c.H, c.L, c.layout);
     if (rc != TGRU_OK) return rc;
-    if (!c.x || !c.y || !c.reserve || !c.workspace || !c.w_ih || !c.w_hh || !c.dw_ih || !c.dw_hh || !c.db_ih ||
-        !c.db_hh)
-        return TGRU_E_NULL;
+    if (!c.x || !c.y || !c.reserve || !c.workspace || !c.w_ih || !c.w_hh) return TGRU_E_NULL;
+    // all four gradient arrays NULL: the caller updates none of these parameters, only dx / dh0 are formed
+    const bool want_w = c.dw_ih || c.dw_hh || c.db_ih || c.db_hh;
+    if (want_w && (!c.dw_ih || !c.dw_hh || !c.db_ih || !c.db_hh)) return TGRU_E_NULL;
     if (c.layout == TGRU_LAYOUT_PACKED && (!c.lengths || !c.toff)) return TGRU_E_LAYOUT;
     if (!aligned16(c.x) || !aligned16(c.y) || !aligned16(c.workspace) || !aligned16(c.reserve) ||
         (c.dy && !aligned16(c.dy)) || (c.dx && !aligned16(c.dx)))
         return TGRU_E_ALIGN;
     for (int l = 0; l < c.L; ++l) {
-        if (!c.w_ih[l] || !c.w_hh[l] || !c.dw_ih[l] || !c.dw_hh[l] || !c.db_ih[l] || !c.db_hh[l]) return TGRU_E_NULL;
+        if (!c.w_ih[l] || !c.w_hh[l]) return TGRU_E_NULL;
+        if (want_w && (!c.dw_ih[l] || !c.dw_hh[l] || !c.db_ih[l] || !c.db_hh[l])) return TGRU_E_NULL;
         if (!aligned16(c.w_ih[l]) || !aligned16(c.w_hh[l])) return TGRU_E_ALIGN;
     }
     if ((c.h0 && !aligned16(c.h0)) || (c.dh_n && !aligned16(c.dh_n)) || (c.dh0 && !aligned16(c.dh0)))
@@ -493,7 +495,9 @@ static void fill_small_bwd(const tgru_backward_args &c, bool vec, SmallBwdArgs &
         b.y_int[l] = y_l; b.gates[l] = reserve_gates(d, res, l);
         b.dg[l] = dg + (size_t)l * dg_stride;
         g.dg[l] = b.dg[l]; g.y_int[l] = y_l;
-        g.dw_ih[l] = c.dw_ih[l]; g.dw_hh[l] = c.dw_hh[l]; g.db_ih[l] = c.db_ih[l]; g.db_hh[l] = c.db_hh[l];
+        if (c.dw_ih) {
+            g.dw_ih[l] = c.dw_ih[l]; g.dw_hh[l] = c.dw_hh[l]; g.db_ih[l] = c.db_ih[l]; g.db_hh[l] = c.db_hh[l];
+        }
     }
     b.dy_ext = c.dy; b.dymap = ext_map(d, c.toff); b.dh_n = c.dh_n; b.h0 = c.h0;
     b.dx_ext = c.dx; b.dxmap = ext_map(d, c.toff); b.In = c.In; b.dh0 = c.dh0; b.db_part = dbp;
@@ -521,6 +525,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     if (rc != TGRU_OK) return rc;
     const bool defer = accumulate == TGRU_DEFER_REDUCE;   // honoured by the one-sequence-per-workgroup path only
     if (defer) accumulate = 0;
+    const bool want_w = dw_ih != nullptr;      // false: no weight / bias gradients (their stages are not launched)
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     const BwdWs w = bwd_ws(d);
@@ -541,11 +546,11 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         if (vec) {
             // the backward kernel accumulates the weight gradients itself: one partial per workgroup
             TGRU_HIP(launch_gru_vec_bwd(b, nullptr, s));
-            if (!defer) TGRU_HIP(launch_gru_small_wgrad_reduce(g, nullptr, s));
+            if (!defer && want_w) TGRU_HIP(launch_gru_small_wgrad_reduce(g, nullptr, s));
             return TGRU_OK;
         }
         TGRU_HIP(launch_gru_small_bwd(b, s));
-        TGRU_HIP(launch_gru_small_wgrad(g, s));
+        if (want_w) TGRU_HIP(launch_gru_small_wgrad(g, s));
         return TGRU_OK;
     }
 
@@ -583,7 +588,9 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&
                                !(l == 0 && layout == TGRU_LAYOUT_PACKED);
         const int db_rows = stepk ? gru_step_bias_rows(B) : mid ? B : nblk;
-        if (mid_wgrad) {       // the weight-gradient reduction sums the bias partials in the same launch
+        if (!want_w) {
+            // nothing: dg only feeds dX below
+        } else if (mid_wgrad) {       // the weight-gradient reduction sums the bias partials in the same launch
             TGRU_HIP(launch_gru_mid_wgrad(dg, in, In_l, l == 0 && layout == TGRU_LAYOUT_BTF, y_l,
                                           h0 ? h0 + (size_t)l * B * H : nullptr, slabs, dw_ih[l], dw_hh[l], B, T,
                                           H, accumulate, dbp, db_rows, db_ih[l], db_hh[l], s));
@@ -591,7 +598,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             TGRU_HIP(launch_bias_grad(dbp, db_rows, H, db_ih[l], db_hh[l], accumulate, s));
         }
         // dW_ih = dgi^T . in   (rows of dg / in are the reduction dimension)
-        if (!mid_wgrad) {
+        if (want_w && !mid_wgrad) {
             int kc;
             const int ns = gemm_split_for(3 * H, In_l, TB, &kc);
             GemmArgs g{};
@@ -604,7 +611,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             TGRU_HIP(launch_slab_reduce(slabs, g.slab_stride, ns, dw_ih[l], (long)3 * H * In_l, accumulate, s));
         }
         // dW_hh = dgh^T . h_prev : dg rows of step t pair with this layer's output rows of step t-1
-        if (!mid_wgrad) {
+        if (want_w && !mid_wgrad) {
             int kc;
             const int K = TB - B;
             const int ns = gemm_split_for(3 * H, H, K > 0 ? K : 1, &kc);
@@ -662,7 +669,8 @@ int tgru_backward_pair(const tgru_backward_args *a, const tgru_backward_args *b,
     fill_small_bwd(*b, true, bb, gb);
     hipStream_t s = (hipStream_t)stream;
     TGRU_HIP(launch_gru_vec_bwd(ba, &bb, s));
-    const bool da = a->accumulate == TGRU_DEFER_REDUCE, db = b->accumulate == TGRU_DEFER_REDUCE;
+    // a call whose reduction is deferred, or that wants no weight gradients, takes no part in the reduce launch
+    const bool da = a->accumulate == TGRU_DEFER_REDUCE || !a->dw_ih, db = b->accumulate == TGRU_DEFER_REDUCE || !b->dw_ih;
     if (!da && !db) TGRU_HIP(launch_gru_small_wgrad_reduce(ga, &gb, s));
     else if (!da) TGRU_HIP(launch_gru_small_wgrad_reduce(ga, nullptr, s));
     else if (!db) TGRU_HIP(launch_gru_small_wgrad_reduce(gb, nullptr, s));
@@ -673,7 +681,7 @@ int tgru_backward_reduce_jobs(const tgru_backward_args *c, tgru_reduce_job *jobs
     if (!c || !jobs) return TGRU_E_NULL;
     int rc = check_backward(*c);
     if (rc != TGRU_OK) return rc;
-    if (c->accumulate != TGRU_DEFER_REDUCE || !use_vec(c->B, c->T, c->In, c->H, c->L, c->layout)) return 0;
+    if (c->accumulate != TGRU_DEFER_REDUCE || !c->dw_ih || !use_vec(c->B, c->T, c->In, c->H, c->L, c->layout)) return 0;
     if (max_jobs < 5 * c->L) return TGRU_E_DIMS;
     SmallBwdArgs b{};
     SmallWgradArgs g{};

@@ -132,12 +132,16 @@ class _GRUFunction(torch.autograd.Function):
                              dtype=torch.float32)
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dh0 = torch.empty_like(h0) if (ctx.has_h0 and ctx.needs_input_grad[1]) else None
-            flat, grads = _alloc_grads(weights)
-            arrays = [_ptr_array(g) for g in _split_weights(weights, L)] + \
-                     [_ptr_array(g) for g in _split_weights(grads, L)]
-            cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays]
+            # no weight of this call wants a gradient (a network the step does not update): the library is
+            # told so (NULL gradient arrays) and forms dx / dh0 only
+            want_w = any(ctx.needs_input_grad[8:])
+            flat, grads = _alloc_grads(weights) if want_w else (None, [None] * len(weights))
+            arrays = [_ptr_array(g) for g in _split_weights(weights, L)]
+            if want_w:
+                arrays += [_ptr_array(g) for g in _split_weights(grads, L)]
+            cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays] + ([] if want_w else [None] * 4)
             queue = deferred.active()
-            defer = queue is not None and queue.may_defer(weights)
+            defer = want_w and queue is not None and queue.may_defer(weights)
             args = BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths), _addr(toff),
                                 *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0), *cast[4:],
                                 B, T, In, H, L, layout, _lib.DEFER_REDUCE if defer else 0)
@@ -206,13 +210,21 @@ class _GRUPairFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         dev = saved[0].device
         keep, args, results = [], [], []
-        all_w = [w for k in range(2) for w in saved[k * (6 + nw) + 6:(k + 1) * (6 + nw)]]
+        # per call: does any weight want a gradient, does anything at all (a call that owes nothing is left out)
+        want_w = [any(ctx.needs_input_grad[1 + k * (4 + nw) + 4:1 + (k + 1) * (4 + nw)]) for k in range(2)]
+        live = [k for k in range(2)
+                if want_w[k] or ctx.needs_input_grad[1 + k * (4 + nw)]
+                or (ctx.meta[k][6] and ctx.needs_input_grad[2 + k * (4 + nw)])]
+        all_w = [w for k in range(2) if want_w[k] for w in saved[k * (6 + nw) + 6:(k + 1) * (6 + nw)]]
         queue = deferred.active()
-        defer = queue is not None and queue.may_defer(all_w)
+        defer = bool(all_w) and queue is not None and queue.may_defer(all_w)
         flag = _lib.DEFER_REDUCE if defer else 0
         with on_device(dev):
             lb = lib()
             for k in range(2):
+                if k not in live:
+                    results.append((None, None, [None] * nw))
+                    continue
                 x, h0, y, lengths, toff, reserve, *weights = saved[k * (6 + nw):(k + 1) * (6 + nw)]
                 B, T, In, H, L, layout, has_h0 = ctx.meta[k]
                 dy, dh_n = douts[2 * k], douts[2 * k + 1]
@@ -223,17 +235,24 @@ class _GRUPairFunction(torch.autograd.Function):
                                  dtype=torch.float32)
                 dx = torch.empty_like(x) if ctx.needs_input_grad[base] else None
                 dh0 = torch.empty_like(h0) if (has_h0 and ctx.needs_input_grad[base + 1]) else None
-                flat, grads = _alloc_grads(weights)
-                arrays = [_ptr_array(g) for g in _split_weights(weights, L)] + \
-                         [_ptr_array(g) for g in _split_weights(grads, L)]
+                flat, grads = _alloc_grads(weights) if want_w[k] else (None, [None] * nw)
+                arrays = [_ptr_array(g) for g in _split_weights(weights, L)]
+                if want_w[k]:
+                    arrays += [_ptr_array(g) for g in _split_weights(grads, L)]
                 keep += arrays + [ws, dy, dh_n, flat]
-                cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays]
+                cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays] + ([] if want_w[k] else [None] * 4)
                 args.append(BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths),
                                          _addr(toff), *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0),
                                          *cast[4:], B, T, In, H, L, layout, flag))
                 results.append((dx, dh0, grads))
-            check(lb.tgru_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
-                  "tgru_backward_pair")
+            if len(args) == 2:
+                check(lb.tgru_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                      "tgru_backward_pair")
+            else:
+                a = args[0]
+                check(lb.tgru_backward(a.dy, a.dh_n, a.x, a.h0, a.y, a.lengths, a.toff, a.w_ih, a.w_hh, a.b_ih, a.b_hh,
+                                       a.reserve, a.workspace, a.dx, a.dh0, a.dw_ih, a.dw_hh, a.db_ih, a.db_hh,
+                                       a.B, a.T, a.In, a.H, a.L, a.layout, a.accumulate, _stream(dev)), "tgru_backward")
             if defer:
                 for a in args:
                     queue.add(lb.tgru_backward_reduce_jobs, a, keep, all_w, dev)

@@ -61,13 +61,15 @@ class _HeadFunction(torch.autograd.Function):
         with on_device(dev):
             lb = lib()
             n = lb.tgru_head_grad_floats(din, dmid, dout)
-            dparams = torch.empty(n, device=dev, dtype=torch.float32)
+            # no parameter wants a gradient (a network the step does not update): dx only
+            want_p = any(ctx.needs_input_grad[2:])
+            dparams = torch.empty(n, device=dev, dtype=torch.float32) if want_p else None
             ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
                              dtype=torch.float32)
             dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
             live = [p for p in params if p is not None]
             queue = deferred.active()
-            defer = queue is not None and queue.may_defer(live)
+            defer = want_p and queue is not None and queue.may_defer(live)
             flag = _lib.DEFER_REDUCE if defer else 0
             check(lb.tgru_head_backward(_ptr(x2), _ptr(dy2), _ptr(dx), M, din, dmid, dout,
                                         *[_ptr(p) for p in params], eps, _ptr(dparams), _ptr(ws), flag,
@@ -76,10 +78,10 @@ class _HeadFunction(torch.autograd.Function):
                 args = HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
                                 *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), flag)
                 queue.add(lb.tgru_head_reduce_jobs, args, [ws, dparams, dy2], live, dev)
-        dg0, db0, dw1, dc1, dg1, db1, dw2, dc2 = _split_grads(dparams, din, dmid, dout, params)
+        grads = _split_grads(dparams, din, dmid, dout, params) if want_p else [None] * 8
         if dx is not None:
             dx = dx.view(dy.shape[:-1] + (din,))
-        return (dx, None, dg0, db0, dw1, dc1, dg1, db1, dw2, dc2)
+        return (dx, None, *grads)
 
 
 def supported(x: torch.Tensor, lin1: nn.Linear, lin2: Optional[nn.Linear], lns=()) -> bool:
@@ -263,28 +265,43 @@ class _HeadPairFunction(torch.autograd.Function):
         with on_device(dev):
             lb = lib()
             heads = []
+            # per head: does any parameter want a gradient, does anything at all (a head that owes nothing is
+            # left out: a network the step does not update, fed by data)
+            want_p = [any(ctx.needs_input_grad[3 + 9 * k:11 + 9 * k]) for k in range(2)]
+            owes = [want_p[k] or ctx.needs_input_grad[2 + 9 * k] for k in range(2)]
             for k in range(2):
                 x2 = saved.pop(0)
                 params = [saved.pop(0) if pres else None for pres in ctx.present[k]]
                 heads.append((x2, params))
-                live += [p for p in params if p is not None]
-            defer = queue is not None and queue.may_defer(live)
+                if want_p[k]:
+                    live += [p for p in params if p is not None]
+            defer = bool(live) and queue is not None and queue.may_defer(live)
             flag = _lib.DEFER_REDUCE if defer else 0
             for k, dy in enumerate((dy_a, dy_b)):
+                if not owes[k]:
+                    results.append((None, [None] * 8))
+                    continue
                 M, din, dmid, dout, eps = ctx.dims[k]
                 x2, params = heads[k]
                 dy2 = dy.contiguous().view(-1, dout)
-                dparams = torch.empty(lb.tgru_head_grad_floats(din, dmid, dout), device=dev, dtype=torch.float32)
+                dparams = torch.empty(lb.tgru_head_grad_floats(din, dmid, dout), device=dev,
+                                      dtype=torch.float32) if want_p[k] else None
                 ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
                                  dtype=torch.float32)
                 dx = torch.empty_like(x2) if ctx.needs_input_grad[2 + 9 * k] else None
                 keep += [dy2, ws, dparams]
                 args.append(HeadArgs(_addr(x2), None, _addr(dy2), _addr(dx), M, din, dmid, dout,
                                      *[_addr(p) for p in params], eps, _addr(dparams), _addr(ws), flag))
-                grads = _split_grads(dparams, din, dmid, dout, params)
+                grads = _split_grads(dparams, din, dmid, dout, params) if want_p[k] else [None] * 8
                 results.append((None if dx is None else dx.view(dy.shape[:-1] + (din,)), grads))
-            check(lb.tgru_head_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
-                  "tgru_head_backward_pair")
+            if len(args) == 2:
+                check(lb.tgru_head_backward_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), _stream(dev)),
+                      "tgru_head_backward_pair")
+            else:
+                a = args[0]
+                check(lb.tgru_head_backward(a.x, a.dy, a.dx, a.M, a.din, a.dmid, a.dout, a.ln0_w, a.ln0_b, a.w1, a.b1,
+                                            a.ln1_w, a.ln1_b, a.w2, a.b2, a.eps, a.dparams, a.workspace,
+                                            a.accumulate, _stream(dev)), "tgru_head_backward")
             if defer:
                 for a in args:
                     queue.add(lb.tgru_head_reduce_jobs, a, keep, live, dev)

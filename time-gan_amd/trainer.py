@@ -7,6 +7,8 @@ batch; the plotting / wandb block of the joint phase (TimeGANv1.py:814-896) is n
 """
 from typing import Dict, List, Optional, Sequence
 
+from contextlib import contextmanager
+
 import torch
 from torch.optim import Adam
 
@@ -129,6 +131,22 @@ class TimeGANTrainer:
         buf.copy_(src)
         return buf
 
+    @contextmanager
+    def _frozen(self, *names):
+        """The networks a sub-step runs through but does not update.  The reference computes their gradients
+        and zeroes them unseen before their next use (TimeGANv1.py:765-769,780-782,796-799; :667-668 for the
+        supervisor phase); here their parameters ask for none, so the weight-gradient kernels of those
+        networks are not launched, and a network fed by data alone (the embedder in the generator and
+        supervisor sub-steps) has no backward pass at all.  The updated parameters are the same."""
+        ps = [p for k in names for p in self.nets[k].parameters() if p.requires_grad]
+        for p in ps:
+            p.requires_grad_(False)
+        try:
+            yield
+        finally:
+            for p in ps:
+                p.requires_grad_(True)
+
     def _zero(self, *names):
         """zero_grad() of the named networks (gradients set to None, torch's default), from cached
         parameter lists: Module.zero_grad() walks the module tree on every call."""
@@ -190,8 +208,8 @@ class TimeGANTrainer:
     def _supervisor_core(self, x):
         n = self.nets
         self._zero("emb", "sup")
-        s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("emb"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
             s_loss.backward(self._one)
         self._sync_grads("sup")
         self._step("sup")
@@ -200,9 +218,9 @@ class TimeGANTrainer:
     def _joint_g_core(self, x, z):
         n = self.nets
         self._zero("emb", "rec", "sup", "g", "d")
-        g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
-                                          group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("emb", "rec", "d"), deferred_reductions():   # one launch sums the partial gradients of the pass
+            g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
+                                              group=self.group)
             g_loss.backward(self._one)
         self._sync_grads("g", "sup")
         self._step("g", "sup")
@@ -211,9 +229,9 @@ class TimeGANTrainer:
     def _joint_e_core(self, x):
         n = self.nets
         self._zero("emb", "rec", "sup")
-        e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
-                                                     group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("sup"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
+                                                         group=self.group)
             e_loss.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_main", "rec")
@@ -270,8 +288,8 @@ class TimeGANTrainer:
             return float(loss)
         n = self.nets
         self._zero("emb", "sup")
-        s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("emb"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
             s_loss.backward(self._one)
         self._sync_grads("sup")
         self._step("sup")
@@ -342,16 +360,16 @@ class TimeGANTrainer:
         for _ in range(10):
             z = noise.pop(0)
             self._zero("emb", "rec", "sup", "g", "d")
-            g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
-                                              group=self.group)
-            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            with self._frozen("emb", "rec", "d"), deferred_reductions():   # one launch sums the pass's partial gradients
+                g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
+                                                  group=self.group)
                 g_loss.backward(self._one)
             out["g_loss"].append(float(g_loss.detach()))
             self._sync_grads("g", "sup")
             self._step("g", "sup")
             self._zero("emb", "rec", "sup")
-            e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
-            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            with self._frozen("sup"), deferred_reductions():     # one launch sums the pass's partial gradients
+                e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
                 e_loss.backward(self._one)
             out["e_loss"].append(float(e_loss.detach()))
             self._sync_grads("emb", "rec")
