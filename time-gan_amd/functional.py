@@ -178,14 +178,16 @@ class _GRUPairFunction(torch.autograd.Function):
         keep, args = [], []
         with on_device(dev):
             lb = lib()
-            for c in calls:
-                B, T, In, H, L, layout = (c[k] for k in ("B", "T", "In", "H", "L", "layout"))
+            for k, c in enumerate(calls):
+                B, T, In, H, L, layout = (c[k_] for k_ in ("B", "T", "In", "H", "L", "layout"))
                 f32 = dict(device=dev, dtype=torch.float32)
+                # the reserve (gate planes, layer outputs) only for a call that will see a backward pass
+                need_k = need_grad and any(ctx.needs_input_grad[1 + k * (4 + nw):1 + (k + 1) * (4 + nw)])
                 c["y"] = torch.empty(c["x"].shape[:-1] + (H,), **f32)
                 c["h_n"] = torch.empty((L, B, H), **f32)
                 ws = torch.empty(lb.tgru_forward_workspace_bytes(B, T, In, H, L) // 4, **f32)
                 c["reserve"] = torch.empty(lb.tgru_reserve_bytes(B, T, In, H, L, layout) // 4, **f32) \
-                    if need_grad else None
+                    if need_k else None
                 arrays = [_ptr_array(g) for g in _split_weights(c["weights"], L)]
                 keep += arrays + [ws]
                 args.append(ForwardArgs(_addr(c["x"]), _addr(c["h0"]), _addr(c["lengths"]), _addr(c["toff"]),
@@ -202,6 +204,11 @@ class _GRUPairFunction(torch.autograd.Function):
         for c in calls:
             saved += [c["x"], c["h0"], c["y"], c["lengths"], c["toff"], c["reserve"], *c["weights"]]
         ctx.save_for_backward(*saved)
+        # autograd takes every output of a Function to depend on every input; a call none of whose own inputs
+        # wants a gradient (a network that is not updated, fed by data) must not drag a backward pass behind it
+        for k in range(2):
+            if not any(ctx.needs_input_grad[1 + k * (4 + nw):1 + (k + 1) * (4 + nw)]):
+                ctx.mark_non_differentiable(calls[k]["y"], calls[k]["h_n"])
         return calls[0]["y"], calls[0]["h_n"], calls[1]["y"], calls[1]["h_n"]
 
     @staticmethod

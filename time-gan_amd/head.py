@@ -254,6 +254,11 @@ class _HeadPairFunction(torch.autograd.Function):
         for h in heads:
             saved += [h["x2"]] + [p for p in h["params"] if p is not None]
         ctx.save_for_backward(*saved)
+        # autograd takes every output of a Function to depend on every input; a head none of whose own inputs
+        # wants a gradient (a network that is not updated, fed by data) must not drag a backward pass behind it
+        for k in range(2):
+            if not any(ctx.needs_input_grad[2 + 9 * k:11 + 9 * k]):
+                ctx.mark_non_differentiable(heads[k]["y"])
         return heads[0]["y"], heads[1]["y"]
 
     @staticmethod
