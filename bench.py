@@ -197,7 +197,8 @@ def cpu_training_baseline(tg, out):
     import torch.nn as nn
     threads = cpu_thread_counts()[-1]
     torch.set_num_threads(threads)
-    rec = {"note": f"build's trainer on torch CPU nn.GRU, sine config F5 H24 L3 T24 B128, {threads} threads"}
+    rec = {"note": f"build's trainer on torch CPU nn.GRU, sine config F5 H24 L3 T24 B128, {threads} threads "
+                   "(like the GPU path it does not form the gradients a sub-step discards; the reference's loop does)"}
     out["cpu_c1"] = rec
     training_probe(tg, torch.device("cpu"), 5, 24, 3, 24, 128, None, False, rec, rnn_cls=nn.GRU)
 
