@@ -195,3 +195,55 @@ def test_training_steps_match_reference_gpu():
 def test_training_steps_hip_graphs_match_reference_gpu():
     """Same fixture with every optimiser sub-step captured into a HIP graph after two eager calls."""
     _steps(torch.device("cuda:0"), True, use_graphs=True)
+
+
+def _updates(device, all_gradients, hidden, rnn_cls=None, graphs=False):
+    """Parameters after one supervisor step and one joint iteration from a fixed start and fixed noise."""
+    import copy
+    import timegan_amd as tg
+    cfg = tg.make_cfg(features=5, hidden=hidden, layers=2, seq_len=8, batch_size=16, device=str(device))
+    torch.manual_seed(5)
+    kw = {} if rnn_cls is None else {"rnn_cls": rnn_cls}
+    tr = tg.TimeGANTrainer(cfg, device=device, all_gradients=all_gradients, use_graphs=graphs, **kw)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(16, 8, 5, generator=g).to(device)
+    noise = [torch.rand(16, 8, 5, generator=g).to(device) for _ in range(11)]
+    out = [tr.supervisor_step(x), tr.embedding_step(x)]
+    res = tr.joint_step(x, noise=noise)
+    out += res["g_loss"] + res["e_loss"] + [res["d_loss"]]
+    return out, {f"{k}.{n}": p.detach().clone() for k, m in tr.nets.items() for n, p in m.named_parameters()}
+
+
+def test_discarded_gradients_do_not_change_the_updates_cpu():
+    """The trainer leaves out the gradients of the networks a sub-step does not update; the losses and every
+    parameter after the steps are those of a trainer that forms them all, as the reference does
+    (TimeGANv1.py:765-790: zero_grad of all five networks, backward, step of two optimisers)."""
+    dev = torch.device("cpu")
+    la, pa = _updates(dev, True, 12, rnn_cls=torch.nn.GRU)
+    lb, pb = _updates(dev, False, 12, rnn_cls=torch.nn.GRU)
+    assert la == lb
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [12, 96])
+def test_discarded_gradients_do_not_change_the_updates_gpu(hidden):
+    """Same on the HIP path: dx-only backward calls (NULL gradient arrays / NULL dparams) and the halves of
+    paired calls that owe nothing leave losses and parameters unchanged -- bit for bit at hidden size 12,
+    where the same kernels run either way; to rounding at 96, where a bottom layer whose input wants no
+    gradient runs the recurrent kernel without the input gradient inside (another summation order, and Adam
+    turns a rounding difference in a tiny gradient into a difference of up to twice the learning rate)."""
+    dev = torch.device("cuda:0")
+    la, pa = _updates(dev, True, hidden)
+    lb, pb = _updates(dev, False, hidden)
+    if hidden == 12:
+        assert la == lb
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), k
+        return
+    for u, v in zip(la, lb):
+        assert abs(u - v) <= 1e-3 * abs(v), (u, v)
+    for k in pa:
+        d = (pa[k] - pb[k]).abs()
+        assert float(d.mean()) < 2e-5 and float(d.max()) < 5e-3, (k, float(d.mean()), float(d.max()))

@@ -59,8 +59,13 @@ class TimeGANTrainer:
     (`emb_opt_side` / `emb_opt_main`, TimeGANv1.py:933-934), each with its own moment estimates.
     """
 
-    def __init__(self, cfg: Dict, device=None, rnn_cls=None, group=None, nets=None, use_graphs: bool = False):
+    def __init__(self, cfg: Dict, device=None, rnn_cls=None, group=None, nets=None, use_graphs: bool = False,
+                 all_gradients: bool = False):
+        """`all_gradients`: also form the gradients of the networks a sub-step runs through but does not
+        update, as the reference does before it zeroes them unseen (see `_frozen`); same parameter updates,
+        more work -- for loops that want to look at those gradients."""
         self.cfg = cfg
+        self.all_gradients = bool(all_gradients)
         self.device = torch.device(device if device is not None else cfg["system"]["device"])
         kw = {} if rnn_cls is None else {"rnn_cls": rnn_cls}
         self.nets = nets if nets is not None else build_networks(cfg, **kw)
@@ -138,7 +143,7 @@ class TimeGANTrainer:
         supervisor phase); here their parameters ask for none, so the weight-gradient kernels of those
         networks are not launched, and a network fed by data alone (the embedder in the generator and
         supervisor sub-steps) has no backward pass at all.  The updated parameters are the same."""
-        ps = [p for k in names for p in self.nets[k].parameters() if p.requires_grad]
+        ps = [] if self.all_gradients else [p for k in names for p in self.nets[k].parameters() if p.requires_grad]
         for p in ps:
             p.requires_grad_(False)
         try:
