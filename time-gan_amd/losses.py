@@ -97,9 +97,11 @@ def embedding_forward_side(emb, rec, x, t, group=None):
     return 10 * torch.sqrt(e_loss_t0), x_tilde
 
 
-def embedding_forward_main(emb, sup, rec, x, t, group=None):
-    """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0)."""
-    h = emb(x, t)
+def embedding_forward_main(emb, sup, rec, x, t, group=None, h=None):
+    """TimeGANv1.py:426-451 -> (e_loss, e_loss0, e_loss_t0).  `h`: emb(x, t) evaluated by the caller with these
+    same weights (it stays in the autograd graph: the embedder's gradients flow through it)."""
+    if h is None:
+        h = emb(x, t)
     x_tilde, h_sup = forward_pair(rec, h, t, sup, h, t)
     out = _fused(loss_ops.EMBED_MAIN, [x_tilde, x, h_sup, h], x, h, group=group)
     if out is not None:
@@ -135,13 +137,17 @@ def discriminator_forward(emb, sup, g, d, x, t, z, gamma=1.0, group=None):
     return d_loss_fake + d_loss_real + gamma * d_loss_fake_e
 
 
-def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None):
-    """TimeGANv1.py:506-553 -> g_loss.
+def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None, h=None):
+    """TimeGANv1.py:506-553 -> g_loss.  `h`: the VALUE of emb(x, t) (detached) when the caller has it already and
+    the embedder's gradients are not wanted from this loss; the embedder is not evaluated then.
 
     The reference also evaluates rec(h) at :521 and overwrites the result at :528 before any use;
     that forward contributes nothing to the loss or to any gradient and is not evaluated here.
     """
-    h, e_hat = forward_pair(emb, x, t, g, z, t)
+    if h is None:
+        h, e_hat = forward_pair(emb, x, t, g, z, t)
+    else:
+        e_hat = g(z, t)
     h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
     both = _batched([h_hat, e_hat], t)
     if both is None:

@@ -220,23 +220,33 @@ class TimeGANTrainer:
         self._step("sup")
         return (s_loss.detach(),)
 
-    def _joint_g_core(self, x, z):
+    def _latent(self, x):
+        """emb(x) for a generator sub-step AND the embedder sub-step that follows it: the generator sub-step
+        updates the generator and the supervisor only (TimeGANv1.py:776-777), so the embedder sub-step's
+        emb(x) (:784) is this very tensor.  It is evaluated once, in grad mode; the generator sub-step reads
+        its value, the embedder sub-step differentiates it.  None when every gradient is wanted (the generator
+        loss then differentiates the embedder too, in a graph of its own, as in the reference)."""
+        if self.all_gradients:
+            return None
+        return self.nets["emb"](x, self.lengths_of(x))
+
+    def _joint_g_core(self, x, z, h=None):
         n = self.nets
         self._zero("emb", "rec", "sup", "g", "d")
         with self._frozen("emb", "rec", "d"), deferred_reductions():   # one launch sums the partial gradients of the pass
             g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
-                                              group=self.group)
+                                              group=self.group, h=None if h is None else h.detach())
             g_loss.backward(self._one)
         self._sync_grads("g", "sup")
         self._step("g", "sup")
         return (g_loss.detach(),)
 
-    def _joint_e_core(self, x):
+    def _joint_e_core(self, x, h=None):
         n = self.nets
         self._zero("emb", "rec", "sup")
         with self._frozen("sup"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
-                                                         group=self.group)
+                                                         group=self.group, h=h)
             e_loss.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_main", "rec")
@@ -267,8 +277,9 @@ class TimeGANTrainer:
         Returns (g_0, e_0, ..., g_9, e_9, d_loss, d_stepped)."""
         outs = []
         for i in range(10):
-            outs += self._joint_g_core(x, zb[i])
-            outs += self._joint_e_core(x)
+            h = self._latent(x)
+            outs += self._joint_g_core(x, zb[i], h)
+            outs += self._joint_e_core(x, h)
         outs += self._joint_d_core(x, zb[10])
         return tuple(outs)
 
@@ -339,9 +350,10 @@ class TimeGANTrainer:
         g_losses, e_losses = [], []
         for _ in range(10):
             z = draw()
-            (g_loss,) = self._joint_g_core(x, z)
+            h = self._latent(x)
+            (g_loss,) = self._joint_g_core(x, z, h)
             g_losses.append(g_loss)
-            (e_loss,) = self._joint_e_core(x)
+            (e_loss,) = self._joint_e_core(x, h)
             e_losses.append(e_loss)
         z = draw()
         n = self.nets
