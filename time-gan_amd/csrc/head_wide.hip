@@ -522,7 +522,7 @@ int workgroups(int M, int waves) {
     return groups < 256 ? groups : 256;
 }
 // waves per workgroup of the backward kernel: two per SIMD where its registers allow (every width <= 96)
-int bwd_waves(int din, int dmid, int dout) { return (din <= 96 && dmid <= 96 && dout <= 96) ? 8 : kWaves; }
+int bwd_waves(int din, int dmid, int dout) { return ((din <= 96 && dmid <= 96 && dout <= 96) || (din <= 32 && dout <= 96)) ? 8 : kWaves; }
 int bwd_workgroups(int M, int din, int dmid, int dout) { return workgroups(M, bwd_waves(din, dmid, dout)); }
 
 // workspace (floats): partial vectors | LayerNorm0 output | ReLU output | gradient at the Linear1 output |
@@ -569,7 +569,7 @@ hipError_t launch(const Args &a, bool backward, hipStream_t s) {
 
 hipError_t dispatch(const Args &a, bool backward, hipStream_t s) {
     if (a.din <= 96 && a.dmid <= 96 && a.dout <= 96) return launch<6, 6, 6, 8>(a, backward, s);   // see bwd_waves
-    if (a.din <= 32 && a.dout <= 96) return launch<2, 12, 6, kWaves>(a, backward, s);
+    if (a.din <= 32 && a.dout <= 96) return launch<2, 12, 6, 8>(a, backward, s);
     return launch<8, 12, 8, kWaves>(a, backward, s);
 }
 
