@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * m96::kBwdWaves) void gru_mid96_bwd_kernel(BwdA
             dgs[(j * 4 + 2) * HS + u] = dgn;
             dgs[(j * 4 + 3) * HS + u] = an;
             dbs[0] += dar; dbs[1] += daz; dbs[2] += an; dbs[3] += dgn;
-            if (pok) {
+            if (pok && a.dg) {       // (no weight gradients wanted: nothing reads the gate gradients after this kernel)
                 float *dg = a.dg + ((long)t * B + b0 + j) * 4 * H + u;
                 dg[0] = dar; dg[H] = daz; dg[2 * H] = an; dg[3 * H] = dgn;
             }

@@ -581,6 +581,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         float *dx_l = l == 0 ? dx : workspace + w.dyb + (size_t)(l & 1) * dyb_stride;
         b.w_ih = w_ih[l]; b.In = In_l; b.dx = dx_l; b.dxmap = l == 0 ? ext_map(d, toff) : id_map(d);
         const bool fused_dx = mid && !stepk && gru_mid96_bwd_supported(b);    // that kernel forms dX itself
+        if (fused_dx && !want_w) b.dg = nullptr;      // neither dX nor a weight-gradient stage will read dg
         if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, s));
         else if (fused_dx) TGRU_HIP(launch_gru_mid96_bwd(b, s));
         else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
