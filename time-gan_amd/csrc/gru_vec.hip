@@ -514,6 +514,7 @@ __global__ __launch_bounds__(320) void gru_vec_bwd_kernel(VecPair<SmallBwdArgs> 
     // result layout of the two-block 32x32x1 MFMA: register 16*blk + rr of lane (hh, jc) holds
     // D[blk][i][jc] with i = 8*(rr/4) + rr%4 + 4*hh
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    if (!a.slabs) return;        // no weight / bias gradients wanted by the caller: nothing will sum the partials
     long off = 0;
     for (int q = 0; q < l; ++q) off += 3L * H * ((q == 0 ? a.In : H) + H);
     float *slab = a.slabs + (long)wg * a.slab_stride + off;

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(VecPair<Args> ga) {
     __shared__ __align__(16) float tiles[6][kRows * kLd];   // two operand tiles; all six for the final column sums
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const bool deep = a.w2 != nullptr;
+    const bool wantp = a.slabs != nullptr;       // false: dx only (no parameter gradients wanted by the caller)
     f32x4 dW1[NM][2], dW2[2][NM];
     float dc1[4 * NM], dg1[4 * NM], db1[4 * NM], dg0[8], db0[8], dc2[8];
 #pragma unroll
@@ -389,9 +390,11 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(VecPair<Args> ga) {
             load_rows<2>(a.dy, a.M, a.dout, row, g, a.vec_out, dy);
 #pragma unroll
             for (int q = 0; q < 8; ++q) dc2[q] += dy[q];
-            tile_put<2>(tiles[0], j, g, dy);
-            tile_put<NM>(tiles[1], j, g, act);
-            outer_acc<2, NM>(tiles[0], tiles[1], a.dout, a.dmid, lane, dW2);
+            if (wantp) {
+                tile_put<2>(tiles[0], j, g, dy);
+                tile_put<NM>(tiles[1], j, g, act);
+                outer_acc<2, NM>(tiles[0], tiles[1], a.dout, a.dmid, lane, dW2);
+            }
             if (!kPre) load_wt<2, NM>(a.w2, a.dout, a.dmid, lane, w2t);
             apply_w<2, NM>(w2t, a.dmid, a.dout, dy, da);
             // ReLU and LayerNorm1
@@ -417,9 +420,11 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(VecPair<Args> ga) {
         // ---- Linear1: dc1, dW1 = dh^T . x1, dx1 = W1^T . dh ------------------------------------------
 #pragma unroll
         for (int q = 0; q < 4 * NM; ++q) dc1[q] += dh[q];
-        tile_put<NM>(tiles[0], j, g, dh);
-        tile_put<2>(tiles[1], j, g, x1);
-        outer_acc<NM, 2>(tiles[0], tiles[1], a.dmid, a.din, lane, dW1);
+        if (wantp) {
+            tile_put<NM>(tiles[0], j, g, dh);
+            tile_put<2>(tiles[1], j, g, x1);
+            outer_acc<NM, 2>(tiles[0], tiles[1], a.dmid, a.din, lane, dW1);
+        }
         if (a.dx || a.g0) {
             float dx[8];
             if (!kPre) load_wt<NM, 2>(a.w1, a.dmid, a.din, lane, w1t);
@@ -443,6 +448,7 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(VecPair<Args> ga) {
     }
 
     // ---- this workgroup's partial parameter gradients -------------------------------------------------
+    if (!wantp) return;
     const GradLayout gl = grad_layout(a.din, a.dmid, a.dout);
     float *slab = a.slabs + (long)wg * a.slab_stride;
     store_dw<NM, 2>(slab + gl.w1, a.dmid, a.din, lane, dW1);
@@ -554,7 +560,7 @@ void head_fill(const tgru_head_args &c, bool backward, head::Args &a) {
         a.dy = c.dy; a.dx = c.dx;
         a.vec_in = (c.din % 4 == 0) && head::aligned16(c.x) && (!c.dx || head::aligned16(c.dx));
         a.vec_out = (c.dout % 4 == 0) && head::aligned16(c.dy);
-        a.slabs = c.workspace; a.slab_stride = head::grad_layout(c.din, c.dmid, c.dout).total;
+        a.slabs = c.dparams ? c.workspace : nullptr; a.slab_stride = head::grad_layout(c.din, c.dmid, c.dout).total;
     } else {
         a.y = c.y;
         a.vec_in = (c.din % 4 == 0) && head::aligned16(c.x);

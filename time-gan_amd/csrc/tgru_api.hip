@@ -506,7 +506,7 @@ static void fill_small_bwd(const tgru_backward_args &c, bool vec, SmallBwdArgs &
     g.B = c.B; g.T = c.T; g.H = c.H; g.L = c.L; g.accumulate = c.accumulate == TGRU_DEFER_REDUCE ? 0 : c.accumulate;
     g.slabs = slabs; g.slab_stride = small_wgrad_slab_floats(c.In, c.H, c.L);
     if (vec) {
-        b.x = c.x; b.xmap = ext_map(d, c.toff); b.slabs = slabs; b.slab_stride = g.slab_stride;
+        b.x = c.x; b.xmap = ext_map(d, c.toff); b.slabs = c.dw_ih ? slabs : nullptr; b.slab_stride = g.slab_stride;
         g.nblk = gru_vec_workgroups(c.B); g.nchunks = g.nblk;
     } else {
         g.nblk = gru_batch_blocks(c.B); g.nchunks = small_wgrad_chunks(c.B, c.T);
