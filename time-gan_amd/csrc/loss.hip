@@ -21,6 +21,7 @@
 // also why the layout does not depend on B).  C = T*F for the generator loss, 0 otherwise.
 #include "../../include/tgru.h"
 #include "tgru_internal.h"
+#include <algorithm>
 
 namespace tgru {
 namespace loss {
@@ -30,6 +31,12 @@ constexpr int kThreads = 256;
 constexpr int kCols = 16;            // columns per moment workgroup (x 16 row lanes)
 
 enum TermType { kNone = 0, kSq = 1, kSqShift = 2, kBceOne = 3, kBceZero = 4 };
+
+// e / d for e < 2^30 and d <= 2^9 by a multiplication with m = ceil(2^40 / d) (exact while e * d < 2^40): the
+// kernels divide an element index by a width per ELEMENT, and a hardware-less 32-bit division is ~40
+// instructions, more than everything else they do per element
+__host__ __device__ inline unsigned long long magic_of(unsigned d) { return ((1ULL << 40) + d - 1) / d; }
+__device__ __forceinline__ unsigned fast_div(unsigned e, unsigned long long m) { return (unsigned)(((unsigned long long)e * m) >> 40); }
 
 struct Layout {
     long cnt, partial, colsum, colsq, out, mean, colstat, nA, nB, total;
@@ -52,7 +59,8 @@ __host__ __device__ inline Layout layout_of(int C) {
 
 struct Args {
     int kind, pass, B, T, H, C;
-    int small;               // every element index fits in 31 bits: 32-bit index arithmetic
+    int small;               // every element index fits in 30 bits, widths in 9: 32-bit indices, divisions by multiplication
+    unsigned long long mH, mT, mTH1, mC;     // magic_of(H), (T), ((T-1)*H), (C)
     int type[3];
     const float *a[3];
     const float *b[3];
@@ -112,7 +120,16 @@ __global__ __launch_bounds__(kThreads) void loss_partial_kernel(Args p) {
         const int k = blockIdx.x / kSlots, j = blockIdx.x % kSlots;
         float s = 0.f;
         if (p.type[k] != kNone) {
-            if (p.small) {
+            if (p.small && p.type[k] == kSqShift) {
+                const unsigned n = (unsigned)p.n[k], th1 = (unsigned)(p.T - 1) * p.H, th = (unsigned)p.T * p.H;
+                const float *a = p.a[k], *b = p.b[k];
+                for (unsigned e = (unsigned)j * kThreads + tid; e < n; e += kSlots * kThreads) {
+                    const unsigned bb = fast_div(e, p.mTH1);
+                    const unsigned ia = bb * th + (e - bb * th1);
+                    const float d = a[ia] - b[ia + p.H];
+                    s += d * d;
+                }
+            } else if (p.small) {
                 const unsigned n = (unsigned)p.n[k];
                 for (unsigned e = (unsigned)j * kThreads + tid; e < n; e += kSlots * kThreads)
                     s += term_value<unsigned>(p.type[k], p.a[k], p.b[k], e, p.T, p.H);
@@ -309,7 +326,8 @@ __global__ __launch_bounds__(kThreads) void loss_backward_kernel(Args p) {
                 const unsigned H = p.H, T = p.T;
 #pragma unroll 4
                 for (unsigned e = (unsigned)j * kThreads + tid; e < (unsigned)n; e += (unsigned)stride) {
-                    const unsigned t = (e / H) % T;
+                    const unsigned row = fast_div(e, p.mH);
+                    const unsigned t = row - fast_div(row, p.mT) * T;
                     if (da) da[e] = t < T - 1 ? 2.f * c * (a[e] - b[e + H]) : 0.f;
                     if (db) db[e] = t >= 1 ? -2.f * c * (a[e - H] - b[e]) : 0.f;
                 }
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void loss_backward_kernel(Args p) {
     const int nmb = gridDim.x - 3 * kSlots;
     if (p.small) {
         for (unsigned e = (blockIdx.x - 3 * kSlots) * kThreads + tid; e < (unsigned)n; e += (unsigned)nmb * kThreads) {
-            const float4 st = *(const float4 *)(p.buf + l.colstat + 4L * (e % (unsigned)p.C));
+            const float4 st = *(const float4 *)(p.buf + l.colstat + 4L * (e - fast_div(e, p.mC) * (unsigned)p.C));
             p.dxh[e] = cm * (st.w + st.z * (p.xh[e] - st.x) / st.y);
         }
         return;
@@ -351,7 +369,14 @@ static int fill_args(Args &a, int kind, const float *const *in, float *const *di
     if (B <= 0 || T <= 0 || H <= 0 || F <= 0) return TGRU_E_DIMS;
     if ((long long)B * T * (H > F ? H : F) >= (1LL << 40)) return TGRU_E_DIMS;
     a.kind = kind; a.B = B; a.T = T; a.H = H; a.C = 0;
-    a.small = (long long)B * T * (H > F ? H : F) < (1LL << 30);     // with room for the grid-stride increment
+    {   // index < 2^30 (room for the grid-stride increment) and index * divisor < 2^40 for every divisor used
+        const long long nmax = (long long)B * T * (H > F ? H : F);
+        const long long dmax = std::max<long long>(std::max<long long>((long long)(T - 1) * H, (long long)T * F),
+                                                   std::max<long long>(H, T));
+        a.small = nmax < (1LL << 30) && nmax * dmax < (1LL << 40);
+    }
+    a.mH = loss::magic_of(H); a.mT = loss::magic_of(T);
+    a.mTH1 = loss::magic_of(T > 1 ? (unsigned)(T - 1) * H : 1u);
     const long nx = (long)B * T * F, nshift = (long)B * (T - 1) * H, ny = (long)B * T;
     int need = 0;
     auto term = [&](int k, int type, int ia, int ib, long n) {
@@ -386,6 +411,7 @@ static int fill_args(Args &a, int kind, const float *const *in, float *const *di
         term(1, kBceOne, 1, -1, ny);
         term(2, kSqShift, 2, 3, nshift);
         a.C = T * F;
+        a.mC = loss::magic_of((unsigned)a.C);
         a.xh = in[4]; a.x = in[5];
         a.dxh = din ? din[4] : nullptr;
         need = 6;
