@@ -62,7 +62,9 @@ def _operands(kind, B, T, H, Fe, gen):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("B,T,H,Fe", [(128, 24, 24, 6), (37, 5, 7, 3), (300, 12, 40, 28)])
+@pytest.mark.parametrize("B,T,H,Fe", [(128, 24, 24, 6), (37, 5, 7, 3), (300, 12, 40, 28),
+                                       (1024, 24, 96, 28),      # the energy config
+                                       (72, 257, 512, 4)])      # index x width beyond 2^40: the 64-bit index path
 def test_fused_loss_matches_torch(kind, B, T, H, Fe):
     from timegan_amd import loss_ops as lo
     gen = torch.Generator(device="cuda:0").manual_seed(100 * kind + B)
