@@ -68,7 +68,8 @@ unsigned long long tgru_launch_count(void);
 
 /*
  * The library reads its kernel-family switches (environment variables TGRU_FORCE_GENERIC, TGRU_NO_VEC,
- * TGRU_NO_MID, TGRU_NO_STEP; "1" selects the alternative kernels) once per process; this
+ * TGRU_NO_MID, TGRU_NO_STEP, TGRU_NO_WIDE_HEAD, ...; "1" selects the alternative kernels; the full list is in
+ * the comment above use_small() in csrc/tgru_api.hip) once per process; this
  * call reads them again.  No reference counterpart.
  */
 void tgru_reload_switches(void);
