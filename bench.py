@@ -351,6 +351,19 @@ def measure_workload(tg, name, steps, warmup, dev, dist, rank, world, do_ar, use
     torch.cuda.synchronize()
     fwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[0], eh[1])) / nh
     bwd_ms_avg = sum(a.elapsed_time(b) for a, b in zip(eh[1], eh[2])) / nh
+    # the gradient all-reduce on its own (a zero bucket of the same size, so that the sums stay finite)
+    ar_ms = None
+    if do_ar:
+        bucket = torch.zeros_like(runner.flat_grads)
+        for _ in range(2):
+            bucket_all_reduce(dist, bucket)
+        device_barrier(dist, dev)
+        n_ar = 20 if bucket.numel() < (1 << 22) else 5
+        t1 = time.perf_counter()
+        for _ in range(n_ar):
+            bucket_all_reduce(dist, bucket)
+        torch.cuda.synchronize()
+        ar_ms = 1e3 * (time.perf_counter() - t1) / n_ar
     if rank != 0:
         return None
 
@@ -391,7 +404,68 @@ def measure_workload(tg, name, steps, warmup, dev, dist, rank, world, do_ar, use
             "config": {"workload": f"{name}: {desc}", "global_batch": world * B, "seq_len": T,
                        "launch": "host-issued kernels" if graph is None else "one HIP graph replay per step",
                        "parallelism": f"dp{world}" + (" + RCCL all-reduce of weight grads" if do_ar else "")},
-            "roofline": roof, "launches_per_step": launches}
+            "roofline": roof, "launches_per_step": launches,
+            "grad_bucket_bytes": int(runner.flat_grads.numel()) * 4,
+            "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4)}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the launcher.  It starts N
+    copies of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as
+    torch.distributed.run would set them), BEFORE anything here has touched a GPU, and never touches one itself.
+    Rank 0's standard output (the one result line) is passed through; the other ranks' goes to standard error.
+    The exit status is non-zero if any rank's is; when one rank fails the others are ended (by process id)."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with status {rc}; ending the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.2)
+    return status
+
+
+def dry_run(args, world, rank, result_fd):
+    """The launcher's plumbing without a GPU: process group over host memory, one all-reduce, one line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    backend = "gloo" if args.backend == "nccl" and not torch.cuda.is_available() else args.backend
+    got = 1
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        got = int(t[0].item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        os.write(result_fd, (json.dumps({"metric": "GRU stack fwd+bwd sequences/sec", "dry_run": True, "n_gpus": world,
+                                         "process_group_ranks": got,
+                                         "backend": backend if world > 1 else None}) + "\n").encode())
+    return 0
 
 
 def main():
@@ -413,14 +487,23 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the multi-rank code path (process group, all-reduces, graph capture of "
                          "them) with a single rank; set TIMEGAN_FORCE_COLLECTIVES=1 as well")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the ranks form the process group, all-reduce one host bucket and rank 0 "
+                         "prints a line with n_gpus and the group size (checks the launcher where there is no GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
     # The result line is the ONLY thing on stdout: libraries that print there (RCCL writes a version banner when
     # its first communicator is built) are sent to stderr at the file-descriptor level.
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.dry_run:
+        return dry_run(args, world, rank, result_fd)
     if os.environ.get("TGRU_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["TGRU_BENCH_WATCHDOG"]), exit=True,
@@ -450,7 +533,15 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
-               "launches_per_step": head["launches_per_step"], "workloads": {args.workload: head}}
+               "launches_per_step": head["launches_per_step"],
+               # data-parallel facts of this run: the backend, the ranks of the process group that carried the
+               # gradient all-reduce (RCCL ranks when the backend is nccl), the bucket and its time on its own
+               "backend": args.backend if multi else None,
+               "rccl_ranks": dist.get_world_size() if (multi and args.backend == "nccl") else 0,
+               "process_group_ranks": dist.get_world_size() if multi else 1,
+               "grad_bucket_bytes": head["grad_bucket_bytes"],
+               "allreduce_ms_per_step": head["allreduce_ms_per_step"],
+               "workloads": {args.workload: head}}
 
     printed = []
 
@@ -521,4 +612,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

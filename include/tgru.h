@@ -74,6 +74,23 @@ unsigned long long tgru_launch_count(void);
  */
 void tgru_reload_switches(void);
 
+/*
+ * Hidden sizes above 128 (multiples of 32) run on persistent kernels whose workgroups hand each other the
+ * state of a time step through memory and therefore must all be resident on the GPU at once.  The library sizes
+ * every launch for an otherwise idle GPU (per XCD: an eighth of the compute units); a kernel of another stream
+ * or process that holds compute units for seconds can still keep a workgroup from starting.  Every wait is
+ * bounded (TGRU_SPIN_LIMIT polls, default 2^24, several seconds), so such a call ends, but with wrong values.
+ * It is never silent: the call's last kernel then writes NaN over the first row of every result of the call
+ * (y and h_n; dx, dh0 and the first row of the weight / bias gradients) and adds one to a counter on that
+ * GPU.  This function returns that counter for the current device -- the number of tgru_forward /
+ * tgru_backward calls whose waits gave up since it was last cleared -- and zeroes it when `clear` is non-zero.
+ * It copies from the device (a host synchronisation): synchronise the streams whose calls are to be counted
+ * first, and do not call it under graph capture.  -1: no gfx950 device, or the copy failed.
+ * TGRU_NO_PERSIST=1 selects one launch per time step instead (no residency requirement).
+ * No reference counterpart.
+ */
+long tgru_persist_timeouts(int clear);
+
 /* Text for a TGRU_E_* code.  No reference counterpart. */
 const char *tgru_error_string(int code);
 

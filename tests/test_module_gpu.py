@@ -230,6 +230,75 @@ def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch)
             assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
+def _raw_stack(tg, B, T, In, H, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / H ** 0.5
+    ws = []
+    for l in range(L):
+        in_l = In if l == 0 else H
+        for shape in ((3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)):
+            ws.append(((torch.rand(shape, generator=g) * 2 - 1) * k).cuda())
+    x = torch.rand(T, B, In, generator=g).cuda()
+    dy = torch.randn(T, B, H, generator=g).cuda()
+    out = tg.gru_forward_backward_raw(x, ws, B, T, tg.LAYOUT_TBF, dy)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_large_hidden_row_tiles_are_resident_per_xcd(monkeypatch):
+    """A persistent launch must fit PER XCD (workgroup ids go round the eight XCDs, each XCD has an eighth of
+    the compute units): 21 row tiles of twelve workgroups (B 2688, H 384) are three row tiles per XCD = 36
+    workgroups for 32 compute units if the launch is sized by the chip's total.  The launcher splits such a
+    batch into launches that fit; the result equals the one-launch-per-step kernels', and no wait timed out."""
+    import timegan_amd as tg
+    for k in ("TGRU_NO_STEP", "TGRU_NO_PERSIST", "TGRU_NO_STEP_DMA", "TGRU_STEP_BWD_WIDE", "TGRU_SPIN_LIMIT"):
+        monkeypatch.delenv(k, raising=False)
+    tg.reload_switches()
+    tg.persist_timeouts()                                   # clear
+    B, T, In, H, L = 2688, 3, 64, 384, 1
+    a = _raw_stack(tg, B, T, In, H, L, 5)
+    assert tg.persist_timeouts() == 0
+    monkeypatch.setenv("TGRU_STEP_BWD_WIDE", "1")           # 128 x 32 backward tiles: twelve workgroups per row tile too
+    tg.reload_switches()
+    w = _raw_stack(tg, B, T, In, H, L, 5)
+    assert tg.persist_timeouts() == 0
+    monkeypatch.delenv("TGRU_STEP_BWD_WIDE")
+    monkeypatch.setenv("TGRU_NO_PERSIST", "1")
+    tg.reload_switches()
+    b = _raw_stack(tg, B, T, In, H, L, 5)
+    monkeypatch.delenv("TGRU_NO_PERSIST")
+    tg.reload_switches()
+    for got in (a, w):
+        assert_close(got["y"].cpu().numpy(), b["y"].cpu().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+        assert_close(got["dx"].cpu().numpy(), b["dx"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+        for i, (p, q) in enumerate(zip(got["grads"], b["grads"])):
+            assert_close(p.cpu().numpy(), q.cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"grad {i}")
+
+
+def test_a_timed_out_wait_of_the_persistent_kernels_is_reported(monkeypatch):
+    """TGRU_SPIN_LIMIT=0 makes every wait of the persistent H > 128 kernels give up at once, which is what a
+    workgroup does whose peers never become resident.  The call must not pass for a good one: the heads of its
+    results are NaN and the device's counter of such calls is non-zero; the next call with the default limit
+    is clean again."""
+    import timegan_amd as tg
+    for k in ("TGRU_NO_STEP", "TGRU_NO_PERSIST", "TGRU_NO_STEP_DMA", "TGRU_STEP_BWD_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TGRU_SPIN_LIMIT", "0")
+    tg.reload_switches()
+    tg.persist_timeouts()
+    out = _raw_stack(tg, 130, 4, 32, 256, 2, 7)
+    assert torch.isnan(out["y"].reshape(-1)[:256]).all() and torch.isnan(out["h_n"].reshape(-1)[:256]).all()
+    assert torch.isnan(out["dx"].reshape(-1)[:32]).all() and torch.isnan(out["grads"][0][0]).all()
+    assert tg.persist_timeouts(clear=False) == 2            # the forward call and the backward call
+    with pytest.raises(tg.TgruError, match="timed-out wait"):
+        tg.check_persist_timeouts()
+    monkeypatch.delenv("TGRU_SPIN_LIMIT")
+    tg.reload_switches()
+    out = _raw_stack(tg, 130, 4, 32, 256, 2, 7)
+    assert tg.persist_timeouts() == 0
+    assert not any(bool(torch.isnan(t).any()) for t in (out["y"], out["h_n"], out["dx"], *out["grads"]))
+
+
 def test_reference_smoke_shapes_lengths_of_one_and_deep_stack():
     """run_embedding_test (TimeGANv1.py:77-94): x (10,150,5), t = ones(10) as a FLOAT tensor,
     H = 100, 50 layers -> (10,150,100); rows past length 1 are emb_linear(norm(0))."""

@@ -65,6 +65,7 @@ SIGNATURES = {
     "tgru_version": (_i, []),
     "tgru_launch_count": (ctypes.c_ulonglong, []),
     "tgru_reload_switches": (None, []),
+    "tgru_persist_timeouts": (ctypes.c_long, [_i]),
     "tgru_error_string": (ctypes.c_char_p, [_i]),
     "tgru_reserve_bytes": (ctypes.c_size_t, [_i] * 6),
     "tgru_forward_workspace_bytes": (ctypes.c_size_t, [_i] * 5),
@@ -148,6 +149,30 @@ def reload_switches():
 def launch_count() -> int:
     """Kernel launches the library has issued in this process so far."""
     return int(lib().tgru_launch_count())
+
+
+def persist_timeouts(device=None, clear: bool = True) -> int:
+    """Calls on `device` (default: the current one) whose persistent H > 128 kernels gave up waiting for each
+    other since the count was last cleared; their results were overwritten with NaN (tgru_persist_timeouts of
+    include/tgru.h).  Synchronises the device first, so every call issued so far is counted."""
+    import torch
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with on_device(device):
+        torch.cuda.synchronize(device)
+        n = int(lib().tgru_persist_timeouts(1 if clear else 0))
+    if n < 0:
+        raise TgruError("tgru_persist_timeouts failed (no gfx950 device, or the device copy failed)")
+    return n
+
+
+def check_persist_timeouts(device=None):
+    """Raises TgruError if a persistent-kernel wait has timed out on `device` since the last check."""
+    n = persist_timeouts(device, clear=True)
+    if n:
+        raise TgruError(
+            f"{n} tgru call(s) on this GPU ended with a timed-out wait of the persistent H > 128 kernels: their "
+            "workgroups were not all resident (another kernel or process held compute units); the results of "
+            "those calls were set to NaN.  TGRU_NO_PERSIST=1 selects kernels without that requirement")
 
 
 def check(code: int, what: str):

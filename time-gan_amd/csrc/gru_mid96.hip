@@ -486,7 +486,9 @@ __global__ __launch_bounds__(64 * m96::kBwdWaves) void gru_mid96_bwd_kernel(BwdA
 
 bool gru_mid96_bwd_supported(const BwdArgs &a) {
     if (switches().no_fuse || a.H != m96::H || a.In != m96::H || !a.dx || !a.w_ih) return false;
-    return a.dxmap.mode != 2;                             // packed rows: the separate product handles them
+    if (a.dxmap.mode == 2) return false;                  // packed rows: the separate product handles them
+    // the loader wave addresses the four gate planes through one buffer descriptor with 32-bit byte offsets
+    return (long)a.T * a.B * m96::H * 16 < (1L << 31);
 }
 
 hipError_t launch_gru_mid96_bwd(const BwdArgs &a, hipStream_t s) {

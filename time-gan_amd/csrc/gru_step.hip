@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(StepFwd s) {
 // the wait; the workgroup's own tile of the previous state / carry stays in registers.
 // All workgroups of a launch must be resident at once: the launcher gives a launch at most one workgroup
 // per CU (a second one does not fit beside the first: registers) and splits larger batches into several
-// launches.  Every wait is bounded: a workgroup that does not see its peers within kSpinLimit polls stops
-// waiting, so the grid always drains (the results are then wrong, and the error word is set).
+// launches.  Every wait is bounded: a workgroup that does not see its peers within `spin_limit` polls stops
+// waiting, so the grid always drains (the results are then wrong: the call's error word is set, and the check
+// kernel that ends the call turns it into NaN results and a count the host can read).
 // ----------------------------------------------------------------------------------------------
 #ifdef TGRU_STAMPS   // diagnostic build only: time (100 MHz ticks) one wave of workgroup 0 spends per phase
 __device__ unsigned long long tgru_stamps_step[16];
@@ -256,7 +257,6 @@ extern "C" int tgru_debug_stamps_step(unsigned long long *out) {
 #define PSTAMP_FLUSH(base)
 #endif
 
-constexpr int kSpinLimit = 1 << 24;
 #ifndef TGRU_PERSIST_DEPTH
 #define TGRU_PERSIST_DEPTH 2
 #endif
@@ -292,18 +292,30 @@ __device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, 
     __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, kAuxSc1);
 }
 
-// One lane of the workgroup waits until `*cnt` has reached `want`; the others wait at the barrier.
-__device__ __forceinline__ void wait_for_peers(unsigned *cnt, unsigned want, unsigned *err) {
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+// The poll of one waiting lane: until `*cnt` has reached `want`, for at most `limit` polls.  A lane that gives up
+// sets the call's error word; every 256th poll looks at that word, so that once one wait of a call has timed
+// out no other wait of the call lasts longer than 256 polls (the results are wrong from then on anyway, and the
+// grid must drain in bounded time).
+__device__ __forceinline__ void poll_peers(unsigned *cnt, unsigned want, unsigned *err, int limit) {
+    if (limit <= 0) {      // (test setting: behave as if the peers never came)
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if (spins > limit ||
+            ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
         }
     }
+}
+
+// One lane of the workgroup waits until `*cnt` has reached `want`; the others wait at the barrier.
+__device__ __forceinline__ void wait_for_peers(unsigned *cnt, unsigned want, unsigned *err, int limit) {
+    if (threadIdx.x == 0) poll_peers(cnt, want, err, limit);
     __syncthreads();
 }
 
@@ -317,8 +329,10 @@ __device__ __forceinline__ void arrive(unsigned *cnt) {
 struct PersistFwd {
     FwdArgs f;
     float *ybuf;          // (T*B, H) time-major buffer the states travel through (y_int, or a time-major y_ext)
-    unsigned *sync;       // sync[0]: error word; sync[1 + mt]: arrivals of row tile mt; all zero at launch
+    unsigned *sync;       // sync[1 + mt]: arrivals of row tile mt, zero at launch
+    unsigned *err;        // error word of the library call this launch belongs to
     int mt0, MT, mtx;     // this launch serves row tiles [mt0, mt0 + MT)
+    int spin_limit;       // polls after which a wait gives up
 };
 
 template <int BK>      // k-tile: 64, or 32 when H is not a multiple of 64
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(256) void gru_persist_fwd_kernel(PersistFwd s) {
 
         const bool have_state = t > 0 || a.h0 != nullptr;
         PSTAMP(0);
-        if (t > 0) wait_for_peers(cnt, (unsigned)(NT * t), s.sync);
+        if (t > 0) wait_for_peers(cnt, (unsigned)(NT * t), s.err, s.spin_limit);
         PSTAMP(1);
         if (have_state) {
             const __amdgpu_buffer_rsrc_t rs_h =
@@ -701,8 +715,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(StepBwd s) {
 
 struct PersistBwd {
     BwdArgs b;
-    unsigned *sync;       // sync[0]: error word; sync[1 + mt]: arrivals of row tile mt; all zero at launch
+    unsigned *sync;       // sync[1 + mt]: arrivals of row tile mt, zero at launch
+    unsigned *err;        // error word of the library call this launch belongs to
     int mt0, MT, mtx;
+    int spin_limit;       // polls after which a wait gives up
 };
 
 // Backward twin of gru_persist_fwd_kernel.  The workgroups of a row tile hand each other the gate gradients
@@ -800,7 +816,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_kernel(PersistBwd s) {
 
         PSTAMP(0);
         if (t < T - 1) {
-            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
+            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.err, s.spin_limit);
             PSTAMP(1);
             // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows; B = W_hh (3H,H)
             const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
@@ -1038,7 +1054,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
             // the W_hh halves of the first tiles depend on nobody: they are requested before the wait for the peers
 #pragma unroll
             for (int d = 0; d < kDepth; ++d) load_b(min(d, nkt - 1) * BK, ring[d]);
-            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.sync);
+            wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.err, s.spin_limit);
 #pragma unroll
             for (int d = 0; d < kDepth; ++d) load_a(min(d, nkt - 1) * BK, ring[d]);
             store_tiles(0, ring[0]);
@@ -1174,18 +1190,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float *lds, int 
     if (aux) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, voff, soff, 0, kAuxSc1);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds, 16, voff, soff, 0, 0);
 }
-// one lane of a loader wave waits until `*cnt` has reached `want` (bounded, see kSpinLimit)
-__device__ __forceinline__ void loader_wait_for_peers(unsigned *cnt, unsigned want, unsigned *err, int lane) {
-    if (lane == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
+// one lane of a loader wave waits until `*cnt` has reached `want` (bounded, see poll_peers)
+__device__ __forceinline__ void loader_wait_for_peers(unsigned *cnt, unsigned want, unsigned *err, int limit, int lane) {
+    if (lane == 0) poll_peers(cnt, want, err, limit);
 }
 }  // namespace pd
 
@@ -1235,7 +1242,7 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(Persi
         }
         const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.w_hh, (long)3 * H * H * 4);
         for (int t = 0; t < T; ++t) {
-            if (t > 0) loader_wait_for_peers(cnt, (unsigned)(NT * t), s.sync, lane);
+            if (t > 0) loader_wait_for_peers(cnt, (unsigned)(NT * t), s.err, s.spin_limit, lane);
             if (t > 0 || a.h0 != nullptr) {
                 const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(t > 0 ? s.ybuf + (long)(t - 1) * B * H : a.h0, step_bytes);
                 auto issue = [&](int kt) {
@@ -1430,32 +1437,118 @@ static int cu_count() {
     return v;
 }
 
-// (one word per row tile of the finest tiling, the backward kernel's 64-sequence tiles, + the error word)
+// Row tiles one persistent launch may serve when a row tile is `nt` workgroups.  Workgroup ids go round the
+// eight XCDs and tile_of() gives XCD x the row tiles x, x + 8, ...: an XCD receives ceil(MT / 8) * nt
+// workgroups of a launch, one per compute unit, and ALL of them must be resident at once (the workgroups of a
+// row tile wait for each other), so the bound is per XCD -- an eighth of the chip's compute units -- and not
+// the chip's total.  0: a row tile does not fit on one XCD, the per-step kernels are used.
+static int persist_row_tiles(int nt) {
+    const int per_xcd = cu_count() / 8;
+    return per_xcd >= nt ? 8 * (per_xcd / nt) : 0;
+}
+
+// (one word per row tile of the finest tiling, the backward kernel's 64-sequence tiles; word 0 is unused)
 size_t gru_step_sync_words(int B) { return 1 + 2 * (size_t)((B + kRows - 1) / kRows); }
 
 // (the persistent kernels address one step's rows through 32-bit buffer offsets: the largest block, a step's
 // rows of dg, must stay below 2 GiB)
 static bool persist_ok(int B, int H, const unsigned *sync) {
-    return sync && !switches().no_persist && cu_count() >= H / kUnits && (long)B * 4 * H * 4 < (1L << 31);
+    return sync && !switches().no_persist && persist_row_tiles(H / kUnits) > 0 && (long)B * 4 * H * 4 < (1L << 31);
+}
+bool gru_step_persistent(int B, int H) {
+    return gru_step_supported(B, H) && !switches().no_persist && persist_row_tiles(H / kUnits) > 0 &&
+           (long)B * 4 * H * 4 < (1L << 31);
 }
 
-hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s) {
+// ----------------------------------------------------------------------------------------------
+// A wait that timed out must not pass unseen.  ONE call of the library has one error word in its workspace: it
+// is zeroed when the call starts (gru_step_begin), set by any wait of any layer that gives up, and looked at by
+// a one-wave kernel at the end of the call (gru_step_check), which then overwrites the head of every result of
+// the call with NaN and adds one to a counter that lives in the library's code object (one copy per GPU) until
+// gru_step_timeouts() reads it.
+// ----------------------------------------------------------------------------------------------
+static __device__ unsigned g_timeouts;     // host code uses timeouts_ptr(), never this name
+
+static unsigned *timeouts_ptr() {
+    constexpr int kMaxDev = 64;
+    static std::atomic<unsigned *> ptr[kMaxDev];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    unsigned *p = ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void *sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_timeouts)) != hipSuccess || !sym) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        p = static_cast<unsigned *>(sym);
+        ptr[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+struct PoisonList {
+    float *p[8];
+    int n[8];
+    int count;
+};
+
+__global__ __launch_bounds__(64) void persist_check_kernel(const unsigned *err, unsigned *timeouts, PoisonList l) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (threadIdx.x == 0) atomicAdd(timeouts, 1u);
+    const float nan = __uint_as_float(0x7fc00000u);
+    for (int k = 0; k < l.count; ++k)
+        for (int i = threadIdx.x; i < l.n[k]; i += 64) l.p[k][i] = nan;
+}
+
+hipError_t gru_step_begin(unsigned *err, hipStream_t s) { return hipMemsetAsync(err, 0, sizeof(unsigned), s); }
+
+hipError_t gru_step_check(const unsigned *err, float *const *outs, const int *ns, int count, hipStream_t s) {
+    unsigned *tp = timeouts_ptr();
+    if (!tp) return hipErrorInvalidValue;
+    PoisonList l{};
+    for (int k = 0; k < count && l.count < 8; ++k)
+        if (outs[k] && ns[k] > 0) { l.p[l.count] = outs[k]; l.n[l.count] = ns[k]; ++l.count; }
+    TGRU_LAUNCH(persist_check_kernel, dim3(1), dim3(64), 0, s, err, tp, l);
+    return hipGetLastError();
+}
+
+long gru_step_timeouts(int clear) {
+    unsigned *tp = timeouts_ptr();
+    if (!tp) return -1;
+    unsigned v = 0;
+    if (hipMemcpy(&v, tp, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (clear && v != 0 && hipMemset(tp, 0, sizeof(v)) != hipSuccess) return -1;
+    return (long)v;
+}
+
+// zero the arrival counters of a layer's launches
+static hipError_t zero_arrivals(unsigned *sync, int B, hipStream_t s) {
+    return hipMemsetAsync(sync, 0, gru_step_sync_words(B) * sizeof(unsigned), s);
+}
+
+hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, unsigned *err, hipStream_t s) {
     // the state of step t-1 is read back from the time-major output of this layer
     float *ysrc = a.y_int ? a.y_int : (a.ymap.mode == 0 ? a.y_ext : nullptr);
     if (!gru_step_supported(a.B, a.H) || !ysrc) return hipErrorInvalidValue;
-    if (persist_ok(a.B, a.H, sync)) {
+    if (err && persist_ok(a.B, a.H, sync)) {
         const int NT = a.H / kUnits, MT = (a.B + kRows - 1) / kRows;
-        const int per_launch = cu_count() / NT;       // row tiles whose workgroups are resident together
-        hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
+        const int per_launch = persist_row_tiles(NT);       // row tiles whose workgroups are resident together
+        hipError_t e = zero_arrivals(sync, a.B, s);
         if (e != hipSuccess) return e;
         for (int mt0 = 0; mt0 < MT; mt0 += per_launch) {
             PersistFwd k;
             k.f = a;
             k.ybuf = ysrc;
             k.sync = sync;
+            k.err = err;
             k.mt0 = mt0;
             k.MT = min(per_launch, MT - mt0);
             k.mtx = (k.MT + 7) / 8;
+            k.spin_limit = switches().spin_limit;
             if (!switches().no_step_dma && a.H % pd::kFwdBK == 0) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<pd::kFwdBK>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
             else if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
             else TGRU_LAUNCH(gru_persist_fwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
@@ -1475,7 +1568,7 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s) 
     return hipGetLastError();
 }
 
-hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
+hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hipStream_t s) {
     if (!gru_step_supported(a.B, a.H) || !carry || !a.y_int) return hipErrorInvalidValue;
     // the persistent kernel keeps the carry in registers: the carry buffer (B x H floats) holds its sync words
     unsigned *sync = reinterpret_cast<unsigned *>(carry);
@@ -1483,22 +1576,25 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
     // batch-major tensor must stay below 2 GiB
     const bool dy_ok = !a.dy_ext || a.dymap.mode == 0 ||
                        (a.dymap.mode == 1 && (long)a.B * a.T * a.H * 4 < (1L << 31));
-    if ((size_t)a.B * a.H >= gru_step_sync_words(a.B) && dy_ok && persist_ok(a.B, a.H, sync)) {
+    if (err && (size_t)a.B * a.H >= gru_step_sync_words(a.B) && dy_ok && persist_ok(a.B, a.H, sync)) {
         const int NT = a.H / kUnits, MT = (a.B + kRows - 1) / kRows;
-        const int per_launch = cu_count() / NT;
-        hipError_t e = hipMemsetAsync(sync, 0, gru_step_sync_words(a.B) * sizeof(unsigned), s);
+        const int per_launch = persist_row_tiles(NT);
+        hipError_t e = zero_arrivals(sync, a.B, s);
         if (e != hipSuccess) return e;
         if (a.H % 64 == 0 && !switches().step_bwd_wide && !(a.dy_int && a.dy_ext)) {
             // 64-sequence x 64-unit tiles; an even number of row tiles, so that every block of 32 sequences the
             // bias partial sums are indexed by gets written (a tile past the batch writes zeros)
-            const int NT2 = a.H / 64, MT2 = 2 * MT, per2 = cu_count() / NT2;
+            const int NT2 = a.H / 64, MT2 = 2 * MT, per2 = persist_row_tiles(NT2);
             for (int mt0 = 0; mt0 < MT2; mt0 += per2) {
                 PersistBwd k;
                 k.b = a;
                 k.sync = sync;
+                k.err = err;
+            k.err = err;
                 k.mt0 = mt0;
                 k.MT = min(per2, MT2 - mt0);
                 k.mtx = (k.MT + 7) / 8;
+                k.spin_limit = switches().spin_limit;
                 TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
             }
             return hipGetLastError();
@@ -1507,9 +1603,11 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s) {
             PersistBwd k;
             k.b = a;
             k.sync = sync;
+            k.err = err;
             k.mt0 = mt0;
             k.MT = min(per_launch, MT - mt0);
             k.mtx = (k.MT + 7) / 8;
+            k.spin_limit = switches().spin_limit;
             if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_bwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
             else TGRU_LAUNCH(gru_persist_bwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
         }

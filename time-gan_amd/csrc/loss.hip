@@ -369,11 +369,14 @@ static int fill_args(Args &a, int kind, const float *const *in, float *const *di
     if (B <= 0 || T <= 0 || H <= 0 || F <= 0) return TGRU_E_DIMS;
     if ((long long)B * T * (H > F ? H : F) >= (1LL << 40)) return TGRU_E_DIMS;
     a.kind = kind; a.B = B; a.T = T; a.H = H; a.C = 0;
-    {   // index < 2^30 (room for the grid-stride increment) and index * divisor < 2^40 for every divisor used
+    {   // index < 2^30 (room for the grid-stride increment), index * divisor < 2^40 for every divisor used (the
+        // quotient is then exact), and index * ceil(2^40 / divisor) < 2^64 (the product in fast_div does not wrap:
+        // index / divisor < 2^24 for the smallest divisor)
         const long long nmax = (long long)B * T * (H > F ? H : F);
         const long long dmax = std::max<long long>(std::max<long long>((long long)(T - 1) * H, (long long)T * F),
                                                    std::max<long long>(H, T));
-        a.small = nmax < (1LL << 30) && nmax * dmax < (1LL << 40);
+        const long long dmin = std::min<long long>(H, T);      // (T - 1) * H and T * F are not smaller than these
+        a.small = nmax < (1LL << 30) && nmax * dmax < (1LL << 40) && nmax < (dmin << 24);
     }
     a.mH = loss::magic_of(H); a.mT = loss::magic_of(T);
     a.mTH1 = loss::magic_of(T > 1 ? (unsigned)(T - 1) * H : 1u);

@@ -27,6 +27,12 @@ void Switches::read() {
     no_wide_head = on("TGRU_NO_WIDE_HEAD");
     gemm_guarded = getenv("TGRU_GEMM_GUARDED") != nullptr;
     gemm_no_dma = getenv("TGRU_GEMM_NO_DMA") != nullptr;
+    // about ten seconds of polling; tests set a tiny limit to see a timeout reported
+    spin_limit = 1 << 24;
+    if (const char *e = getenv("TGRU_SPIN_LIMIT")) {
+        const long v = strtol(e, nullptr, 10);      // 0: every wait gives up at once (tests of the report path)
+        if (e[0] != 0 && v >= 0 && v <= (1L << 30)) spin_limit = (int)v;
+    }
 }
 Switches &switches() {
     static Switches s;
@@ -82,6 +88,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
 //   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
+//   TGRU_SPIN_LIMIT=n     H > 128: polls after which a wait of a persistent kernel gives up (default 2^24)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
 //   TGRU_NO_WIDE_HEAD=1   heads beyond 32 / 64 wide are not taken by the fused kernels of head_wide.hip
 //   TGRU_GEMM_GUARDED=1   bounds-checked operand loads in gemm_kernel
@@ -140,12 +147,16 @@ float *reserve_y(const Dims &d, float *r, int l) {   // l < L-1, or l == L-1 whe
 
 // forward workspace: gi | packed W_hh | two ping-pong layer outputs (inference without reserve)
 size_t fwd_ws_floats(const Dims &d) {
-    return align64(d.TB() * 3 * d.H) + align64(packed_whh_floats(d.H)) + 2 * align64(d.TBH());
+    return align64(d.TB() * 3 * d.H) + align64(packed_whh_floats(d.H)) + 2 * align64(d.TBH()) + kStepStatusFloats;
+}
+// (the error word of the persistent H > 128 kernels sits behind the ping-pong buffers)
+float *fwd_ws_status(const Dims &d, float *ws) {
+    return ws + align64(d.TB() * 3 * d.H) + align64(packed_whh_floats(d.H)) + 2 * align64(d.TBH());
 }
 
 
 // backward workspace: dg | 2 x dy ping-pong | packed W_hh^T | bias partials | split-K slabs
-struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, total; int max_slabs; };
+struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, status, total; int max_slabs; };
 BwdWs bwd_ws(const Dims &d) {
     BwdWs w;
     size_t off = 0;
@@ -183,6 +194,7 @@ BwdWs bwd_ws(const Dims &d) {
     }
     w.slabs = off; off += align64(slab_floats);
     w.carry = off; off += gru_step_supported(d.B, d.H) ? align64((size_t)d.B * d.H) : 0;   // per-step kernels only
+    w.status = off; off += kStepStatusFloats;      // error word of the persistent H > 128 kernels
     w.total = off;
     return w;
 }
@@ -241,6 +253,11 @@ int tgru_version(void) { return 200; }
 unsigned long long tgru_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 void tgru_reload_switches(void) { switches().read(); }
+
+long tgru_persist_timeouts(int clear) {
+    if (device_ok() != TGRU_OK) return -1;
+    return gru_step_timeouts(clear);
+}
 
 const char *tgru_error_string(int code) {
     switch (code) {
@@ -368,6 +385,9 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         return TGRU_OK;
     }
 
+    // persistent H > 128 kernels: the call's error word starts at zero
+    unsigned *err = use_step(B, H) && gru_step_persistent(B, H) ? reinterpret_cast<unsigned *>(fwd_ws_status(d, workspace)) : nullptr;
+    if (err) TGRU_HIP(gru_step_begin(err, s));
     const float *in = x;
     for (int l = 0; l < L; ++l) {
         const int In_l = l == 0 ? In : H;
@@ -403,11 +423,16 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.lengths = lengths;
         f.B = B; f.T = T; f.H = H;
         // (the packed-W_hh region of the workspace is free on this path: it holds the sync words)
-        if (stepk) TGRU_HIP(launch_gru_step_fwd(f, reinterpret_cast<unsigned *>(wp), s));
+        if (stepk) TGRU_HIP(launch_gru_step_fwd(f, reinterpret_cast<unsigned *>(wp), err, s));
         else if (fused) TGRU_HIP(launch_gru_mid96_fwd(f, s));
         else if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
         else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;
+    }
+    if (err) {     // a wait that gave up: NaN at the head of y and h_n, one more in tgru_persist_timeouts()
+        float *outs[2] = {y, h_n};
+        const int ns[2] = {H, H};
+        TGRU_HIP(gru_step_check(err, outs, ns, 2, s));
     }
     return TGRU_OK;
 }
@@ -554,6 +579,9 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         return TGRU_OK;
     }
 
+    // persistent H > 128 kernels: the call's error word starts at zero
+    unsigned *err = use_step(B, H) && gru_step_persistent(B, H) ? reinterpret_cast<unsigned *>(workspace + w.status) : nullptr;
+    if (err) TGRU_HIP(gru_step_begin(err, s));
     for (int l = L - 1; l >= 0; --l) {
         const int In_l = l == 0 ? In : H;
         const bool top = l == L - 1;
@@ -582,7 +610,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         b.w_ih = w_ih[l]; b.In = In_l; b.dx = dx_l; b.dxmap = l == 0 ? ext_map(d, toff) : id_map(d);
         const bool fused_dx = mid && !stepk && gru_mid96_bwd_supported(b);    // that kernel forms dX itself
         if (fused_dx && !want_w) b.dg = nullptr;      // neither dX nor a weight-gradient stage will read dg
-        if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, s));
+        if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, err, s));
         else if (fused_dx) TGRU_HIP(launch_gru_mid96_bwd(b, s));
         else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
         else TGRU_HIP(launch_gru_bwd(b, s));
@@ -645,6 +673,13 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             g.cmap = l == 0 ? ext_map(d, toff) : id_map(d);
             TGRU_HIP(launch_gemm(g, true, false, 1, s));
         }
+    }
+    if (err) {     // a wait that gave up: NaN at the head of every gradient of the call
+        float *outs[8] = {dx, dh0, want_w ? dw_ih[0] : nullptr, want_w ? dw_hh[0] : nullptr,
+                          want_w ? db_ih[0] : nullptr, want_w ? db_hh[0] : nullptr,
+                          want_w ? dw_ih[L - 1] : nullptr, want_w ? dw_hh[L - 1] : nullptr};
+        const int ns[8] = {In, H, In, H, H, H, H, H};
+        TGRU_HIP(gru_step_check(err, outs, ns, 8, s));
     }
     return TGRU_OK;
 }

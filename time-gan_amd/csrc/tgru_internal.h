@@ -22,6 +22,7 @@ extern std::atomic<unsigned long long> g_launches;
 // them again.
 struct Switches {
     bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, step_bwd_wide, no_wide_head;
+    int spin_limit;     // polls after which a wait of the persistent H > 128 kernels gives up (TGRU_SPIN_LIMIT)
     void read();
     Switches() { read(); }
 };
@@ -243,8 +244,20 @@ int gru_step_bias_rows(int B);
 // the kernel, the workgroups of a row tile wait for each other through counters); null, or TGRU_NO_PERSIST=1,
 // selects one launch per step.
 size_t gru_step_sync_words(int B);
-hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, hipStream_t s);
-hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, hipStream_t s);
+// `err`: the call's error word (see gru_step_begin); null selects one launch per step as well.
+hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, unsigned *err, hipStream_t s);
+hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hipStream_t s);
+// Will a call of these dimensions run on the persistent kernels (with the current switches and device)?
+bool gru_step_persistent(int B, int H);
+// One library call has one error word (a 32-bit word of its workspace): a wait of a persistent kernel that gives
+// up sets it.  gru_step_begin zeroes it before the first layer; gru_step_check, after the last layer, launches
+// one wave that -- if the word is set -- fills the first ns[k] floats of every outs[k] (null entries skipped, at
+// most 8) with NaN and counts the call in a per-device counter; gru_step_timeouts returns that counter
+// (synchronous copy from the device; -1 on failure) and zeroes it on request.
+constexpr size_t kStepStatusFloats = 64;      // workspace set aside for the error word
+hipError_t gru_step_begin(unsigned *err, hipStream_t s);
+hipError_t gru_step_check(const unsigned *err, float *const *outs, const int *ns, int count, hipStream_t s);
+long gru_step_timeouts(int clear);
 
 // H, In <= 32, one sequence per workgroup on the vector ALU (gru_vec.hip); the backward kernel also
 // leaves per-workgroup partial weight / bias gradients in a.slabs / a.db_part for the reduce stage
