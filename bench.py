@@ -21,7 +21,7 @@ backward, timed with HIP events on the launch stream) against the bound of the w
 H = 24, fp32 MFMA FLOPs for H >= 96.  `cpu_baseline` times the operator the reference itself calls
 (torch.nn.GRU on CPU behind pack_padded_sequence) on the host cores of the same box, on a bounded sample of
 the same workload, median of five steps per thread count; CPU model and core counts are stated.
-If anything after the headline measurement stalls past TGRU_BENCH_DEADLINE seconds (default 400), rank 0
+If anything after the headline measurement stalls past TGRU_BENCH_DEADLINE seconds (default 600), rank 0
 prints the line with what has been measured and `"stalled": true`, and every rank exits with status 3.
 """
 import os
@@ -53,7 +53,7 @@ WORKLOADS = {
 # (steps, warmup) of a workload when it is not the headline
 SUB_STEPS = {"c2": (200, 20), "c3": (100, 10), "c4": (10, 2)}
 # features of the training probes at the workloads' dimensions (stock: 6, energy: 28)
-TRAIN_FEATURES = {"c2": 6, "c3": 28}
+TRAIN_FEATURES = {"c1": 5, "c2": 6, "c3": 28}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
 
@@ -111,13 +111,16 @@ def cpu_thread_counts():
 
 def cpu_baseline(B, T, In, H, L, repeats=5):
     """torch.nn.GRU CPU fwd+bwd through pack/pad, as the reference calls it: median of `repeats` steps per
-    thread count on a bounded sample of the workload (the stress shape: 32 sequences x the first 32 of the
-    256 steps, the result scaled to full-length sequences -- the work is linear in T)."""
+    thread count on a bounded sample of the workload (the stress shape: 256 sequences x the first 16 of the
+    256 steps, the result scaled to full-length sequences -- the work is linear in T; a batch of 256 keeps the
+    CPU's GEMMs fed, the figure is still a lower bound for the full batch of 2048)."""
     import torch.nn as nn
     results = []
     heavy = B * T * H > 1024 * 24 * 96
-    Bc, Tc = (32, 32) if heavy else (B, T)
-    for threads in cpu_thread_counts():
+    Bc, Tc = (min(B, 256), min(T, 16)) if heavy else (B, T)
+    if heavy:
+        repeats = 3
+    for threads in (cpu_thread_counts()[-1:] if heavy else cpu_thread_counts()):
         torch.set_num_threads(threads)
         torch.manual_seed(42)
         gru = nn.GRU(In, H, L, batch_first=True)
@@ -147,11 +150,12 @@ def cpu_baseline(B, T, In, H, L, repeats=5):
             "sample": (f"torch {torch.__version__} CPU nn.GRU (the operator the reference calls) behind "
                        f"pack_padded_sequence/pad_packed_sequence, fwd+bwd, {Bc} sequences x {Tc} of {T} steps, "
                        f"same H/L, median of {repeats} steps after warm-up, OMP_PROC_BIND=close"
-                       + (", scaled to full-length sequences" if Tc != T else "") + "; thread counts tried: "
+                       + (", scaled to full-length sequences (throughput per sequence depends on the batch: a lower "
+                          "bound for the full batch)" if Tc != T else "") + "; thread counts tried: "
                        + ", ".join(f"{r['threads']}t={r['seqs_per_s']:.1f}/s" for r in results))}
 
 
-def training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3, rnn_cls=None):
+def training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3, rnn_cls=None, count=False):
     """Secondary figure: 3-phase TimeGAN steps (TimeGANv1.py:573-812 loop bodies).
     One joint iteration = 10 x (generator step + embedder step) + 1 discriminator step
     = 116 GRU-stack forwards + 103 backwards plus the heads / losses / Adam work around them.
@@ -185,9 +189,152 @@ def training_probe(tg, dev, features, H, L, T, B, group, graphs, out, iters=3, r
             torch.cuda.synchronize()
         out[f"{prefix}{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 3)
         if on_gpu and not graphs:
-            # the library's own launches (GRU, heads, losses, reductions, Adam); torch's elementwise kernels
-            # around them are not counted here (the rocprof kernel trace under profiles/ has the total)
+            # the library's own launches (GRU, heads, losses, reductions, Adam); all GPU kernels of an iteration,
+            # torch's elementwise / cat / fill kernels included, are counted by the profiler below
             out[f"{name}_tgru_launches_per_iter"] = round((tg.launch_count() - n0) / n, 1)
+    if count:
+        key = "joint_gpu_kernels_per_iter" if on_gpu else "joint_aten_ops_per_iter"
+        out[("hipgraph_" if graphs else "") + key] = count_ops(lambda: tr.joint_step(x), on_gpu)
+
+
+def count_ops(fn, device_kernels):
+    """Runs fn() once under torch's profiler.  device_kernels: the number of GPU kernels it launched (torch's own
+    elementwise / copy / fill kernels included, not only the library's); otherwise the number of ATen operator
+    invocations on the CPU -- the CPU path's analogue of a launch count.  None if the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if device_kernels else [])
+        with profile(activities=acts) as prof:
+            fn()
+            if device_kernels:
+                torch.cuda.synchronize()
+        n = 0
+        for e in prof.events():
+            is_dev = str(getattr(e, "device_type", "")).endswith("CUDA")
+            if device_kernels and is_dev:
+                n += 1
+            elif not device_kernels and not is_dev and str(e.name).startswith("aten::"):
+                n += 1
+        return n
+    except Exception as exc:       # noqa: BLE001 -- a diagnostic must not end the benchmark
+        return f"unavailable: {type(exc).__name__}: {exc}"[:160]
+
+
+def generation_and_scoring(tg, dev, out, cpu_leg):
+    """The water-quality configuration's path (6 features, T 24, H 24, 3 layers): generation = the inference path
+    g(z) -> sup -> rec (TimeGANv1.py:556-570), three stack FORWARDS per sequence, and the post-hoc scorer
+    (metrics/GeneralRNN.py:27-55 with the GRU cell, data flow of metrics/discriminative.py:57-78): a one-layer GRU
+    classifier trained real-vs-synthetic, at the TimeGAN-paper width (In 6 -> H 24) and at the reference's own
+    scorer config (In 28 -> H 256, discriminative.py:8-20)."""
+    import numpy as np
+    import torch.nn as nn
+    F, H, L, T, N = 6, 24, 3, 24, 8000
+    cfg = tg.make_cfg(features=F, hidden=H, layers=L, seq_len=T, device=str(dev))
+    torch.manual_seed(42)
+    tr = tg.TimeGANTrainer(cfg, device=dev)
+    z = torch.rand(N, T, F, device=dev)
+    for _ in range(3):
+        tr.generate(z)
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n0 = tg.launch_count()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        tr.generate(z)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    dev_ms = e0.elapsed_time(e1) / reps
+    gru_bytes = 3 * N * 8.0 * L * T * H + 3 * 4.0 * L * (6 * H * H + 6 * H)      # forward only: read x, write y
+    rec = {"config": f"generation: {N} sequences through g -> sup -> rec (3 stack forwards), F {F} H {H} L {L} T {T}",
+           "value": round(N / wall, 1), "unit": "seqs/s", "ms_per_pass": round(1e3 * wall, 4),
+           "device_ms_per_pass": round(dev_ms, 4), "tgru_launches_per_pass": (tg.launch_count() - n0) // reps,
+           "roofline": {"bound": "hbm", "achieved": round(gru_bytes / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gru_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes_per_pass": gru_bytes,
+                        "note": "forward-only GRU bytes (8 L T H per sequence and stack) over the whole pass, heads included in the time"}}
+    out["generation"] = rec
+    rng = np.random.default_rng(0)
+    scorers = {}
+    out["scorer_training"] = scorers
+    for name, (n, f, hidden) in {"in6_h24": (8000, 6, 24), "in28_h256": (1000, 28, 256)}.items():
+        real = rng.uniform(0, 1, (n, T, f)).astype(np.float32)
+        synth = rng.uniform(0, 1, (n, T, f)).astype(np.float32)
+        tg.scorer.discriminative_score(real, synth, dev, hidden=hidden, steps=5, batch=128)      # warm-up
+        torch.cuda.synchronize()
+        steps = 100
+        t0 = time.perf_counter()
+        tg.scorer.discriminative_score(real, synth, dev, hidden=hidden, steps=steps, batch=128)
+        torch.cuda.synchronize()
+        r = {"config": f"GRU classifier In {f} -> H {hidden}, 1 layer, T {T}, minibatch 128, Adam; {n} + {n} windows",
+             "value": round(steps / (time.perf_counter() - t0), 1), "unit": "training steps/s (evaluation of the test split included)"}
+        if cpu_leg:
+            torch.set_num_threads(cpu_thread_counts()[-1])
+            t0 = time.perf_counter()
+            tg.scorer.discriminative_score(real, synth, "cpu", hidden=hidden, steps=20, batch=128, rnn_cls=nn.GRU)
+            r["cpu_baseline"] = {"value": round(20 / (time.perf_counter() - t0), 1), "unit": "training steps/s",
+                                 "cores": cpu_thread_counts()[-1], "kind": "reference",
+                                 "sample": "the same scorer on torch CPU nn.GRU, 20 steps"}
+        scorers[name] = r
+    if cpu_leg:
+        torch.set_num_threads(cpu_thread_counts()[-1])
+        cfgc = tg.make_cfg(features=F, hidden=H, layers=L, seq_len=T, device="cpu")
+        trc = tg.TimeGANTrainer(cfgc, device="cpu", rnn_cls=nn.GRU)
+        zc = torch.rand(2000, T, F)
+        trc.generate(zc)
+        t0 = time.perf_counter()
+        trc.generate(zc)
+        rec["cpu_baseline"] = {"value": round(2000 / (time.perf_counter() - t0), 1), "unit": "seqs/s",
+                               "cores": cpu_thread_counts()[-1], "kind": "reference",
+                               "sample": "the same inference path on torch CPU nn.GRU, 2000 sequences"}
+
+
+def stress_training(tg, dev, out):
+    """The three training phases at the stress configuration's dimensions (64 features, H 512, L 3, T 256) on one
+    GPU: the per-GPU batch is the largest of 2048 / 1024 / 512 / 256 that the memory holds, judged from the peak of a
+    joint iteration at batch 256 (everything a joint iteration keeps alive grows linearly with the batch)."""
+    F, H, L, T = 64, 512, 3, 256
+    cfg = tg.make_cfg(features=F, hidden=H, layers=L, seq_len=T, device=str(dev))
+    torch.manual_seed(42)
+    tr = tg.TimeGANTrainer(cfg, device=dev)
+    total = torch.cuda.get_device_properties(dev).total_memory
+    rec = {"config": f"{F} features, H {H}, L {L}, T {T}"}
+    out["c4"] = rec
+
+    def one(B, timed_joint):
+        x = torch.rand(B, T, F, device=dev)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        res = {}
+        for name, fn, n in (("embedding", tr.embedding_step, 2), ("supervisor", tr.supervisor_step, 2),
+                            ("joint", tr.joint_step, timed_joint)):
+            fn(x)                                   # warm-up (allocator growth, first launches)
+            torch.cuda.synchronize()
+            n0 = tg.launch_count()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn(x)
+            torch.cuda.synchronize()
+            res[f"{name}_iters_per_s"] = round(n / (time.perf_counter() - t0), 4)
+            res[f"{name}_tgru_launches_per_iter"] = round((tg.launch_count() - n0) / n, 1)
+        res["peak_memory_GiB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
+        del x
+        torch.cuda.empty_cache()
+        return res
+
+    small = one(256, 1)
+    rec["batch_256"] = small
+    per_seq = small["peak_memory_GiB"] * 2 ** 30 / 256
+    B = next((b for b in (2048, 1024, 512) if per_seq * b < 0.85 * total), None)
+    if B is not None:
+        rec[f"batch_{B}"] = one(B, 1)
+    rec["per_gpu_batch"] = B or 256
+    rec["persist_timeouts"] = tg.persist_timeouts()
+    rec["note"] = ("eager mode; one joint iteration = 84 stack forwards + 81 backwards at these dimensions, heads on the "
+                   "library's GEMMs and wave-per-row LayerNorm kernels (no vendor GEMM, no torch LayerNorm)")
+
 
 
 def cpu_training_baseline(tg, out):
@@ -200,7 +347,7 @@ def cpu_training_baseline(tg, out):
     rec = {"note": f"build's trainer on torch CPU nn.GRU, sine config F5 H24 L3 T24 B128, {threads} threads "
                    "(like the GPU path it does not form the gradients a sub-step discards; the reference's loop does)"}
     out["cpu_c1"] = rec
-    training_probe(tg, torch.device("cpu"), 5, 24, 3, 24, 128, None, False, rec, rnn_cls=nn.GRU)
+    training_probe(tg, torch.device("cpu"), 5, 24, 3, 24, 128, None, False, rec, rnn_cls=nn.GRU, count=True)
 
 
 def device_barrier(dist, dev):
@@ -564,7 +711,7 @@ def main():
         sys.stdout.flush()
         os._exit(3)
 
-    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "400")) + (0 if rank == 0 else 5), give_up)
+    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "600")) + (0 if rank == 0 else 5), give_up)
     watchdog.daemon = True
     watchdog.start()
 
@@ -584,11 +731,11 @@ def main():
         if rank == 0:
             out["timegan_training"] = training
         group = dist.group.WORLD if multi else None
-        for name in ("c2", "c3"):
-            B, T, _, H, L, _ = WORKLOADS[name]
+        for name in ("c1", "c2", "c3"):
+            B, T, _, H, L, _ = WORKLOADS["c2" if name == "c1" else name]
             rec = {"config": f"{TRAIN_FEATURES[name]} features, H {H}, L {L}, T {T}, batch {B} per GPU"}
             training[name] = rec
-            training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, False, rec)
+            training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, False, rec, count=not multi)
             if multi and args.backend != "nccl":
                 rec["hipgraph_note"] = "graph mode with collectives inside needs the RCCL backend"
             elif multi:
@@ -596,11 +743,19 @@ def main():
                     child_graph_probe(args.backend, rank, world, rec)
             else:
                 training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, True, rec)
+        if not multi:
+            stress_training(tg, dev, training)
         if rank == 0 and world == 1 and not args.no_cpu:
             cpu_training_baseline(tg, training)
+    if not multi and not args.only:
+        c5 = {}
+        out["workloads"]["c5"] = c5
+        generation_and_scoring(tg, dev, c5, not args.no_cpu)
 
     if rank == 0 and world == 1 and not args.no_cpu:
         for name, rec in out["workloads"].items():
+            if name not in WORKLOADS:
+                continue
             B, T, In, H, L, _ = WORKLOADS[name]
             rec["cpu_baseline"] = cpu_baseline(B, T, In, H, L)
         out["cpu_baseline"] = out["workloads"][args.workload]["cpu_baseline"]

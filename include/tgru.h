@@ -185,12 +185,16 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
                           int M, int N, int K, tgru_stream_t stream);
 
 /*
- * LayerNorm over the last dimension, rows of `width` floats (a multiple of 4, at most 128): the
+ * LayerNorm over the last dimension, rows of `width` floats (a multiple of 4, at most 1024): the
  * nn.LayerNorm(dim_hidden) stages of the heads (outdated_files/TimeGANv1.py:45,67) at hidden sizes the
  * fused head kernels do not cover.  forward: y = (x - mean) * rstd * gamma + beta, stats[2r] = mean,
  * stats[2r + 1] = rstd (biased variance + eps, torch.nn.functional.layer_norm).  backward: dx (NULL: not
  * wanted), dgamma / dbeta (NULL: not wanted; accumulate 0 / 1) from x, dy and the saved stats; `workspace`
  * holds one partial column sum per workgroup, added in a fixed order.  gamma / beta may be NULL (1 / 0).
+ * The _act_ forms take `relu` (0 / 1): with 1 they are LayerNorm followed by ReLU in one pass -- the
+ * `nn.LayerNorm, nn.ReLU` pair inside every feature MLP (outdated_files/TimeGANv1.py:45-46,122-123,201-202,
+ * 280-281) -- forward y = max(LayerNorm(x), 0); backward takes dy with respect to THAT y, recomputes the
+ * pre-activation from x, the stats, gamma and beta and lets dy pass where it was positive.
  */
 int tgru_layer_norm_supported(int width);
 size_t tgru_layer_norm_backward_workspace_bytes(long rows, int width);
@@ -199,6 +203,28 @@ int tgru_layer_norm_forward(const float *x, const float *gamma, const float *bet
 int tgru_layer_norm_backward(const float *x, const float *dy, const float *stats, const float *gamma, float *dx,
                              float *dgamma, float *dbeta, float *workspace, long rows, int width, int accumulate,
                              tgru_stream_t stream);
+int tgru_layer_norm_act_forward(const float *x, const float *gamma, const float *beta, float *y, float *stats,
+                                long rows, int width, float eps, int relu, tgru_stream_t stream);
+int tgru_layer_norm_act_backward(const float *x, const float *dy, const float *stats, const float *gamma,
+                                 const float *beta, float *dx, float *dgamma, float *dbeta, float *workspace,
+                                 long rows, int width, int relu, int accumulate, tgru_stream_t stream);
+
+/*
+ * out (width) (=|+=) the sum of the rows of a (rows, width): the bias gradient autograd forms for a Linear
+ * layer (outdated_files/TimeGANv1.py:39-50) from the gradient of its output.  width as for
+ * tgru_layer_norm_supported; one partial per workgroup in `workspace`, added in a fixed order; accumulate 0 / 1.
+ */
+size_t tgru_column_sum_workspace_bytes(long rows, int width);
+int tgru_column_sum(const float *a, float *out, float *workspace, long rows, int width, int accumulate,
+                    tgru_stream_t stream);
+
+/*
+ * Input gradient of a Linear layer:  dx (rows, in_f) = dy (rows, out_f) . w (out_f, in_f), fp32 MFMA GEMM;
+ * the product autograd forms for the Linear layers around the GRU (outdated_files/TimeGANv1.py:39-50,67-68)
+ * at widths the fused head kernels do not cover.  (The layer's forward is tgru_input_projection.)
+ */
+int tgru_linear_input_grad(const float *dy, const float *w, float *dx, int rows, int out_f, int in_f,
+                           tgru_stream_t stream);
 
 /*
  * Weight gradient of a Linear layer over many rows:  dw (out_f, in_f) (=|+=) dy (rows, out_f)^T . x (rows, in_f),

@@ -76,8 +76,22 @@ def test_stress_stack_full_size_is_consistent_with_its_parts():
 def test_three_phase_steps_at_the_energy_dimensions():
     """28 features, H 96, L 3, batch 64: one embedding, one supervisor and one joint step (10 x (G + E) + D)
     on the HIP path against the same trainer on torch's CPU nn.GRU, same parameters, same noise."""
+    _three_phase_steps(28, 96, 3, 24, 64, 24, 64)
+
+
+@pytest.mark.timeout(900)
+def test_three_phase_steps_at_the_stress_dimensions(monkeypatch):
+    """64 features, H 512, L 3, T 256 (the stress configuration) at batch 8: one embedding, one supervisor and
+    one joint step on the HIP path -- persistent H > 128 recurrences, heads on the library's GEMMs and
+    wave-per-row LayerNorms -- against the trainer on torch's CPU nn.GRU (about a minute of CPU time)."""
+    import timegan_amd.head as head
+    monkeypatch.setattr(head, "WIDE_LINEAR_MIN_ROWS", 1)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    _three_phase_steps(64, 512, 3, 256, 8, 256, 8)
+
+
+def _three_phase_steps(F, H, L, T, B, T_joint, B_joint):
     import timegan_amd as tg
-    F, H, L, T, B = 28, 96, 3, 24, 64
     cfg = tg.make_cfg(features=F, hidden=H, layers=L, seq_len=T, device="cpu")
     torch.manual_seed(21)
     cpu = tg.TimeGANTrainer(cfg, device="cpu", rnn_cls=nn.GRU)
@@ -87,18 +101,20 @@ def test_three_phase_steps_at_the_energy_dimensions():
     x = torch.rand(B, T, F, generator=g)
     noise = [torch.rand(B, T, F, generator=g) for _ in range(11)]
 
-    def check_params(tag, rtol, atol_abs):
+    def check_params(tag, rtol, atol_abs, worst=2.2):
         # Adam moves a parameter by about lr = 1e-3 per step whatever the gradient's size: a rounding-level
         # difference in a near-zero gradient shows up as a fraction of lr, hence the absolute term.  A network's
         # FIRST Adam step is exactly +-lr per element, so an element whose gradient is rounding noise around
-        # zero can land 2 lr from the reference: at most one element in 5000 may do that, none may exceed it.
+        # zero can land 2 lr from the reference: at most one element in 5000 may do that, none may exceed it
+        # (`worst` lr: a joint iteration updates a network ten times, and among the 786 432 elements of a 512-wide
+        # weight matrix a few noise-level ones drift a little further than after one update).
         lr = 1e-3
         for k in cpu.nets:
             for (name, pc), (_, pg) in zip(cpu.nets[k].state_dict().items(), gpu.nets[k].state_dict().items()):
                 got, ref = pg.cpu().numpy().astype(np.float64), pc.numpy().astype(np.float64)
                 err = np.abs(got - ref)
                 bad = err > atol_abs + rtol * np.abs(ref)
-                assert bad.sum() <= max(1, bad.size // 5000) and float(err.max(initial=0.0)) <= 2.2 * lr + atol_abs, \
+                assert bad.sum() <= max(1, bad.size // 5000) and float(err.max(initial=0.0)) <= worst * lr + atol_abs, \
                     (f"{tag} {k}.{name}: {int(bad.sum())}/{bad.size} elements out of tolerance, "
                      f"max abs err {err.max():.3e}, max |ref| {np.abs(ref).max():.3e}")
 
@@ -108,10 +124,18 @@ def test_three_phase_steps_at_the_energy_dimensions():
     ls_c, ls_g = cpu.supervisor_step(x), gpu.supervisor_step(x.cuda())
     assert_close([ls_g], [ls_c], 1e-4, 0, "supervisor loss")
     check_params("after supervisor step", 1e-3, 1e-4)
+    if (T_joint, B_joint) != (T, B):        # the joint step on shorter sequences (seq_len is read per call)
+        for tr in (cpu, gpu):
+            tr.seq_len = T_joint
+            for net in tr.nets.values():
+                net.seq_len = T_joint
+        x = x[:B_joint, :T_joint].contiguous()
+        noise = [z[:B_joint, :T_joint].contiguous() for z in noise]
     oc = cpu.joint_step(x, noise=[z.clone() for z in noise])
     og = gpu.joint_step(x.cuda(), noise=[z.cuda() for z in noise])
     assert_close(og["g_loss"], oc["g_loss"], 1e-3, 0, "joint g losses")
     assert_close(og["e_loss"], oc["e_loss"], 1e-3, 0, "joint e losses")
     assert_close([og["d_loss"]], [oc["d_loss"]], 1e-3, 0, "joint d loss")
     assert og["d_stepped"] == oc["d_stepped"]
-    check_params("after joint step", 5e-3, 5e-4)
+    check_params("after joint step", 5e-3, 5e-4, worst=2.2 if H <= 128 else 4.0)
+    assert tg.persist_timeouts() == 0

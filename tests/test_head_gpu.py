@@ -149,6 +149,67 @@ def test_wide_head_weight_gradient_split_over_rows(rows, din, dmid, dout, monkey
             assert_close(po.grad.cpu().numpy(), pr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"d{k}.{name}")
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("rows,width", [(2304, 512), (2051, 1024), (4100, 160), (2048, 768), (3000, 96), (2500, 132)])
+def test_layer_norm_up_to_1024_wide_with_relu(rows, width, relu):
+    """The wave-per-row LayerNorm kernels (widths above 128, and any width with the ReLU in the same pass):
+    relu(LayerNorm(x)) and its gradients against torch on the CPU, the stress configuration's widths included
+    (512; 1024 inside the generator's feature MLP)."""
+    from timegan_amd.head import wide_layer_norm
+    torch.manual_seed(rows + width)
+    ref = nn.LayerNorm(width)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    ours = copy.deepcopy(ref).to("cuda:0")
+    x = torch.randn(rows, width) * 2 + 0.5
+    dy = torch.randn(rows, width)
+    xr = x.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True)
+    yr = torch.relu(ref(xr)) if relu else ref(xr)
+    yo = wide_layer_norm(xo, ours, relu=relu)
+    (yr * dy).sum().backward()
+    (yo * dy.cuda()).sum().backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    assert_close(ours.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dgamma")
+    assert_close(ours.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dbeta")
+
+
+@pytest.mark.parametrize("rows,din,dmid,dout,ln0", [(2304, 64, 512, 512, False),     # embedder's feature MLP at H 512
+                                                     (2304, 64, 1024, 512, False),    # generator's
+                                                     (2304, 512, 512, 64, True),      # recovery's output stage
+                                                     (2304, 512, 512, 512, True),     # supervisor's
+                                                     (2304, 160, 160, 160, True)])
+def test_heads_at_the_stress_widths_run_on_the_library(rows, din, dmid, dout, ln0):
+    """Heads beyond the fused kernels' widths (hidden size 512): every product on the library's GEMMs, LayerNorm
+    (+ ReLU) on its wave-per-row kernels, bias gradients as column sums -- no vendor GEMM and no torch
+    LayerNorm launch -- against torch on the CPU at the standard bar."""
+    import timegan_amd as tg
+    from timegan_amd.head import head_apply, supported
+    ref = _modules(din, dmid, dout, ln0, True, seed=5)
+    ours = {k: (None if v is None else copy.deepcopy(v).to("cuda:0")) for k, v in ref.items()}
+    g = torch.Generator().manual_seed(11)
+    x = _off_the_kink(ref, torch.rand(rows, din, generator=g), g)
+    dy = torch.randn(rows, dout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xo = x.clone().cuda().requires_grad_(True)
+    assert not supported(xo, ours["lin1"], ours["lin2"])
+    yr = _torch_head(ref, xr)
+    n0 = tg.launch_count()
+    yo = head_apply(xo, ours["ln0"], ours["lin1"], ours["ln1"], ours["lin2"])
+    assert tg.launch_count() - n0 == (4 if ln0 else 3)       # [LN0], GEMM, LN1 + ReLU, GEMM
+    (yr * dy).sum().backward()
+    (yo * dy.cuda()).sum().backward()
+    assert_close(yo.detach().cpu().numpy(), yr.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    for k in ref:
+        if ref[k] is None:
+            continue
+        for (name, pr), (_, po) in zip(ref[k].named_parameters(), ours[k].named_parameters()):
+            assert_close(po.grad.cpu().numpy(), pr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"d{k}.{name}")
+
+
 @pytest.mark.parametrize("rows,width,affine", [(4096, 96, True), (2051, 28, True), (3000, 128, True), (2500, 4, True),
                                                  (2048, 64, False)])
 def test_wide_layer_norm_matches_torch_cpu(rows, width, affine):

@@ -80,6 +80,11 @@ SIGNATURES = {
     "tgru_layer_norm_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long, _i]),
     "tgru_layer_norm_forward": (_i, [_vp] * 5 + [ctypes.c_long, _i, ctypes.c_float, _vp]),
     "tgru_layer_norm_backward": (_i, [_vp] * 8 + [ctypes.c_long, _i, _i, _vp]),
+    "tgru_layer_norm_act_forward": (_i, [_vp] * 5 + [ctypes.c_long, _i, ctypes.c_float, _i, _vp]),
+    "tgru_layer_norm_act_backward": (_i, [_vp] * 9 + [ctypes.c_long, _i, _i, _i, _vp]),
+    "tgru_column_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long, _i]),
+    "tgru_column_sum": (_i, [_vp] * 3 + [ctypes.c_long, _i, _i, _vp]),
+    "tgru_linear_input_grad": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
     "tgru_linear_weight_grad_workspace_bytes": (ctypes.c_size_t, [_i] * 3),
     "tgru_linear_weight_grad": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "tgru_head_supported": (_i, [_i] * 4),

@@ -306,6 +306,22 @@ int tgru_input_projection(const float *a, const float *w, const float *bias, flo
     return TGRU_OK;
 }
 
+int tgru_linear_input_grad(const float *dy, const float *w, float *dx, int rows, int out_f, int in_f,
+                           tgru_stream_t stream) {
+    if (rows <= 0 || out_f <= 0 || in_f <= 0) return TGRU_E_DIMS;
+    if (!dy || !w || !dx) return TGRU_E_NULL;
+    // dx (rows, in_f) = dy (rows, out_f) . w (out_f, in_f): the reduction runs along dy's contiguous index and
+    // down w's rows, the shape of the dX product of tgru_backward
+    GemmArgs g{};
+    g.A = dy; g.lda = out_f; g.Bm = w; g.ldb = in_f; g.C = dx; g.ldc = in_f; g.bias = nullptr;
+    g.M = rows; g.N = in_f; g.K = out_f; g.kchunk = out_f; g.slab_stride = 0; g.accumulate = 0;
+    g.amap = RowMap{0, 1, 1, nullptr};
+    g.bmap = g.amap;
+    g.cmap = g.amap;
+    TGRU_HIP(launch_gemm(g, true, false, 1, (hipStream_t)stream));
+    return TGRU_OK;
+}
+
 size_t tgru_linear_weight_grad_workspace_bytes(int rows, int out_f, int in_f) {
     if (rows <= 0 || out_f <= 0 || in_f <= 0) return 0;
     int kc;

@@ -107,7 +107,7 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
     assert (ln1 is None) == (lin2 is None)
     if not supported(x, lin1, lin2, (ln0, ln1)):
         h = wide_linear(x if ln0 is None else wide_layer_norm(x, ln0), lin1)
-        return h if lin2 is None else wide_linear(torch.relu(wide_layer_norm(h, ln1)), lin2)
+        return h if lin2 is None else wide_linear(wide_layer_norm(h, ln1, relu=True), lin2)
     eps = (ln0 or ln1).eps if (ln0 is not None or ln1 is not None) else 1e-5
     if ln0 is not None and ln1 is not None:
         assert ln0.eps == ln1.eps
@@ -119,95 +119,121 @@ def head_apply(x: torch.Tensor, ln0: Optional[nn.LayerNorm], lin1: nn.Linear,
 
 
 class _WideLinearFunction(torch.autograd.Function):
-    """y = x W^T + b for heads wider than the fused kernels cover.  Forward and dx are torch's GEMMs; the
-    weight gradient dy^T x, a (out x in) product over B*T rows, goes through tgru_linear_weight_grad, which
-    splits it over the rows (the vendor GEMM picks an unsplit 32 x 32 tiling for it: 9 workgroups)."""
+    """y = x W^T + b for heads wider than the fused kernels cover, every product on the library's fp32 MFMA
+    GEMMs: forward (tgru_input_projection), dx = dy W (tgru_linear_input_grad), the weight gradient dy^T x -- an
+    (out x in) product over B*T rows, split over the rows (tgru_linear_weight_grad) -- and the bias gradient as a
+    column sum (tgru_column_sum)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w = w.contiguous()
+        ctx.save_for_backward(x2, w)
+        ctx.xshape = x.shape
+        if _TORCH_WIDE_GEMMS:
+            return torch.nn.functional.linear(x, w, b)
+        y = torch.empty(x.shape[:-1] + (w.shape[0],), device=x.device, dtype=torch.float32)
+        with on_device(x.device):
+            check(lib().tgru_input_projection(_ptr(x2), _ptr(w), _ptr(None if b is None else b.contiguous()), _ptr(y),
+                                              x2.shape[0], w.shape[0], w.shape[1], _stream(x.device)),
+                  "tgru_input_projection")
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        rows, out_f, in_f = dy2.shape[0], w.shape[0], w.shape[1]
+        dev = x2.device
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = (dy2 @ w).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1]).contiguous()
-            rows, out_f, in_f = dy2.shape[0], w.shape[0], w.shape[1]
-            dw = torch.empty_like(w, memory_format=torch.contiguous_format)
-            lb = lib()
-            ws = torch.empty(max(1, lb.tgru_linear_weight_grad_workspace_bytes(rows, out_f, in_f) // 4),
-                             device=x.device, dtype=torch.float32)
-            with on_device(x.device):
-                stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        lb = lib()
+        with on_device(dev):
+            stream = _stream(dev)
+            if ctx.needs_input_grad[0]:
+                if _TORCH_WIDE_GEMMS:
+                    dx = (dy2 @ w).view(ctx.xshape)
+                else:
+                    dx = torch.empty(ctx.xshape, device=dev, dtype=torch.float32)
+                    check(lb.tgru_linear_input_grad(_ptr(dy2), _ptr(w), _ptr(dx), rows, out_f, in_f, stream),
+                          "tgru_linear_input_grad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                ws = torch.empty(max(1, lb.tgru_linear_weight_grad_workspace_bytes(rows, out_f, in_f) // 4),
+                                 device=dev, dtype=torch.float32)
                 check(lb.tgru_linear_weight_grad(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(ws), rows, out_f, in_f, 0, stream),
                       "tgru_linear_weight_grad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if out_f % 4 == 0 and lb.tgru_layer_norm_supported(out_f):
+                    db = torch.empty(out_f, device=dev, dtype=torch.float32)
+                    ws = torch.empty(max(1, lb.tgru_column_sum_workspace_bytes(rows, out_f) // 4), device=dev,
+                                     dtype=torch.float32)
+                    check(lb.tgru_column_sum(_ptr(dy2), _ptr(db), _ptr(ws), rows, out_f, 0, stream), "tgru_column_sum")
+                else:
+                    db = dy2.sum(0)
         return dx, dw, db
 
 
 class _WideLayerNormFunction(torch.autograd.Function):
-    """nn.LayerNorm over the last dimension (width a multiple of 4, at most 128) on tgru_layer_norm_forward /
-    tgru_layer_norm_backward: each tensor crosses HBM once per pass."""
+    """nn.LayerNorm over the last dimension (width a multiple of 4, at most 1024), optionally followed by ReLU in
+    the same pass, on tgru_layer_norm_act_forward / _backward: each tensor crosses HBM once per pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, relu):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         y = torch.empty_like(x2)
         stats = torch.empty(2 * x2.shape[0], device=x.device, dtype=torch.float32)
         with on_device(x.device):
-            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            check(lib().tgru_layer_norm_forward(_ptr(x2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), x2.shape[0],
-                                                x2.shape[1], float(eps), stream), "tgru_layer_norm_forward")
-        ctx.save_for_backward(x2, stats, gamma)
-        ctx.has_beta = beta is not None
+            check(lib().tgru_layer_norm_act_forward(_ptr(x2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), x2.shape[0],
+                                                    x2.shape[1], float(eps), int(relu), _stream(x.device)),
+                  "tgru_layer_norm_act_forward")
+        ctx.save_for_backward(x2, stats, gamma, beta)
+        ctx.relu = int(relu)
         ctx.shape = x.shape
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, stats, gamma = ctx.saved_tensors
+        x2, stats, gamma, beta = ctx.saved_tensors
         rows, width = x2.shape
         dy2 = dy.reshape(rows, width).contiguous()
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
-        dbeta = torch.empty(width, device=x2.device, dtype=torch.float32) if (ctx.has_beta and ctx.needs_input_grad[2]) else None
+        dbeta = torch.empty(width, device=x2.device, dtype=torch.float32) if (beta is not None and ctx.needs_input_grad[2]) else None
         lb = lib()
         ws = torch.empty(max(1, lb.tgru_layer_norm_backward_workspace_bytes(rows, width) // 4), device=x2.device,
                          dtype=torch.float32)
         with on_device(x2.device):
-            stream = ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
-            check(lb.tgru_layer_norm_backward(_ptr(x2), _ptr(dy2), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dgamma),
-                                              _ptr(dbeta), _ptr(ws), rows, width, 0, stream), "tgru_layer_norm_backward")
-        return (None if dx is None else dx.view(ctx.shape)), dgamma, dbeta, None
+            check(lb.tgru_layer_norm_act_backward(_ptr(x2), _ptr(dy2), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dx),
+                                                  _ptr(dgamma), _ptr(dbeta), _ptr(ws), rows, width, ctx.relu, 0,
+                                                  _stream(x2.device)), "tgru_layer_norm_act_backward")
+        return (None if dx is None else dx.view(ctx.shape)), dgamma, dbeta, None, None
 
 
 WIDE_LINEAR_MIN_ROWS = 2048
+# A/B switch for measurements: True keeps torch's (vendor) GEMMs for y and dx of the heads beyond the fused
+# kernels; the library still forms their weight / bias gradients and LayerNorms
+_TORCH_WIDE_GEMMS = False
 
 
-def wide_layer_norm(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
-    """ln(x); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on and for widths the library covers, through the
-    library's LayerNorm kernels."""
+def wide_layer_norm(x: torch.Tensor, ln: nn.LayerNorm, relu: bool = False) -> torch.Tensor:
+    """ln(x), or relu(ln(x)); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on and for widths the library covers,
+    through the library's LayerNorm kernels (one pass, the ReLU included)."""
     width = x.shape[-1]
     rows = x.numel() // max(1, width)
     if (x.is_cuda and x.dtype == torch.float32 and rows >= WIDE_LINEAR_MIN_ROWS and len(ln.normalized_shape) == 1
             and ln.normalized_shape[0] == width and lib().tgru_layer_norm_supported(width)
             and (ln.weight is None or ln.weight.dtype == torch.float32)):
-        return _WideLayerNormFunction.apply(x, ln.weight, ln.bias, ln.eps)
-    return ln(x)
+        return _WideLayerNormFunction.apply(x, ln.weight, ln.bias, ln.eps, relu)
+    return torch.relu(ln(x)) if relu else ln(x)
 
 
 def wide_linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
-    """lin(x); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on, with the row-split weight gradient."""
+    """lin(x); on the GPU, from WIDE_LINEAR_MIN_ROWS rows on, through the library's GEMMs.  A layer that asks for
+    no gradient at all (no_grad, frozen parameters and a constant input) still takes the library's forward."""
     rows = x.numel() // max(1, x.shape[-1])
     if (x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32 and rows >= WIDE_LINEAR_MIN_ROWS
-            and torch.is_grad_enabled() and lin.weight.requires_grad):
+            and rows < (1 << 29)):
         return _WideLinearFunction.apply(x, lin.weight, lin.bias)
     return lin(x)
 
