@@ -101,20 +101,22 @@ def _three_phase_steps(F, H, L, T, B, T_joint, B_joint):
     x = torch.rand(B, T, F, generator=g)
     noise = [torch.rand(B, T, F, generator=g) for _ in range(11)]
 
-    def check_params(tag, rtol, atol_abs, worst=2.2):
+    def check_params(tag, rtol, atol_abs, worst=2.2, rare=5000):
         # Adam moves a parameter by about lr = 1e-3 per step whatever the gradient's size: a rounding-level
         # difference in a near-zero gradient shows up as a fraction of lr, hence the absolute term.  A network's
         # FIRST Adam step is exactly +-lr per element, so an element whose gradient is rounding noise around
         # zero can land 2 lr from the reference: at most one element in 5000 may do that, none may exceed it
         # (`worst` lr: a joint iteration updates a network ten times, and among the 786 432 elements of a 512-wide
-        # weight matrix a few noise-level ones drift a little further than after one update).
+        # weight matrix a few drift further: Adam turns ANY non-zero gradient into a step of about lr, so a
+        # weight fed by a ReLU unit that is dead on the CPU and rounding-level alive on the GPU moves up to lr per
+        # update, ten updates; `rare`: one element in that many may be out of tolerance).
         lr = 1e-3
         for k in cpu.nets:
             for (name, pc), (_, pg) in zip(cpu.nets[k].state_dict().items(), gpu.nets[k].state_dict().items()):
                 got, ref = pg.cpu().numpy().astype(np.float64), pc.numpy().astype(np.float64)
                 err = np.abs(got - ref)
                 bad = err > atol_abs + rtol * np.abs(ref)
-                assert bad.sum() <= max(1, bad.size // 5000) and float(err.max(initial=0.0)) <= worst * lr + atol_abs, \
+                assert bad.sum() <= max(1, bad.size // rare) and float(err.max(initial=0.0)) <= worst * lr + atol_abs, \
                     (f"{tag} {k}.{name}: {int(bad.sum())}/{bad.size} elements out of tolerance, "
                      f"max abs err {err.max():.3e}, max |ref| {np.abs(ref).max():.3e}")
 
@@ -137,5 +139,5 @@ def _three_phase_steps(F, H, L, T, B, T_joint, B_joint):
     assert_close(og["e_loss"], oc["e_loss"], 1e-3, 0, "joint e losses")
     assert_close([og["d_loss"]], [oc["d_loss"]], 1e-3, 0, "joint d loss")
     assert og["d_stepped"] == oc["d_stepped"]
-    check_params("after joint step", 5e-3, 5e-4, worst=2.2 if H <= 128 else 4.0)
+    check_params("after joint step", 5e-3, 5e-4, worst=2.2 if H <= 128 else 10.5, rare=5000 if H <= 128 else 1000)
     assert tg.persist_timeouts() == 0

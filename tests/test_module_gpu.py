@@ -176,20 +176,25 @@ def test_energy_width_with_initial_state_and_ragged_lengths(switches, batch_firs
         assert_close(q_.grad.cpu().numpy(), p_.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, tag + " d" + name)
 
 
-@pytest.mark.parametrize("family", ["persistent_tiles", "persistent_tiles_staged", "persistent_tiles_wide_backward",
-                                    "launch_per_step", "sixteen_sequences"])
+@pytest.mark.parametrize("family", ["persistent_tiles", "persistent_tiles_unfused", "persistent_tiles_staged",
+                                    "persistent_tiles_wide_backward", "launch_per_step", "sixteen_sequences"])
 def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch):
     """H > 128 in multiples of 32 runs on 128-sequence x 32-unit tiles with the time loop inside the kernel
     (the workgroups of a row tile synchronise through counters; the forward kernel's operand tiles are fetched
-    by loader waves, TGRU_NO_STEP_DMA=1 stages them through registers; the backward kernel works on 64 x 64
+    by loader waves and the layer's input projection runs inside it where the input width is a multiple of 32,
+    TGRU_NO_STEP_FUSE=1 leaves the projection to the batched GEMM, TGRU_NO_STEP_DMA=1 stages the tiles through
+    registers; the backward kernel works on 64 x 64
     tiles where H is a multiple of 64, TGRU_STEP_BWD_WIDE=1 keeps it on 128 x 32); TGRU_NO_PERSIST=1 gives the
     same tiles with one launch per time step, TGRU_NO_STEP=1 the 16-sequence kernels: all on the same cases."""
     import timegan_amd as tg
     monkeypatch.delenv("TGRU_NO_STEP", raising=False)
     monkeypatch.delenv("TGRU_NO_PERSIST", raising=False)
     monkeypatch.delenv("TGRU_NO_STEP_DMA", raising=False)
+    monkeypatch.delenv("TGRU_NO_STEP_FUSE", raising=False)
     monkeypatch.delenv("TGRU_STEP_BWD_WIDE", raising=False)
-    if family == "persistent_tiles_staged":
+    if family == "persistent_tiles_unfused":
+        monkeypatch.setenv("TGRU_NO_STEP_FUSE", "1")
+    elif family == "persistent_tiles_staged":
         monkeypatch.setenv("TGRU_NO_STEP_DMA", "1")
     elif family == "persistent_tiles_wide_backward":
         monkeypatch.setenv("TGRU_STEP_BWD_WIDE", "1")
@@ -243,6 +248,49 @@ def _raw_stack(tg, B, T, In, H, L, seed):
     out = tg.gru_forward_backward_raw(x, ws, B, T, tg.LAYOUT_TBF, dy)
     torch.cuda.synchronize()
     return out
+
+
+@pytest.mark.parametrize("B,T,In,H,L,ragged,with_h0", [(300, 1, 64, 256, 2, False, False),     # one step: projection only
+                                                        (300, 2, 32, 160, 3, True, False),     # one-tile projection
+                                                        (130, 6, 512, 512, 2, True, True),
+                                                        (257, 5, 96, 384, 2, False, True)])
+def test_large_hidden_forward_with_the_projection_inside(B, T, In, H, L, ragged, with_h0, monkeypatch):
+    """The persistent forward kernel that computes the layer's input projection itself (between a step's stores and
+    the next step's recurrent product) against the same kernels fed by the batched projection GEMM: time-major
+    rows through the C ABI, with and without an initial state, uniform and ragged lengths, a single step."""
+    import timegan_amd as tg
+    for k in ("TGRU_NO_STEP", "TGRU_NO_PERSIST", "TGRU_NO_STEP_DMA", "TGRU_NO_STEP_FUSE", "TGRU_STEP_BWD_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    g = torch.Generator().manual_seed(B + T)
+    k = 1.0 / H ** 0.5
+    ws = []
+    for l in range(L):
+        in_l = In if l == 0 else H
+        for shape in ((3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)):
+            ws.append(((torch.rand(shape, generator=g) * 2 - 1) * k).cuda())
+    x = torch.rand(T, B, In, generator=g).cuda()
+    dy = torch.randn(T, B, H, generator=g).cuda()
+    h0 = torch.randn(L, B, H, generator=g).cuda() if with_h0 else None
+    lens = None
+    if ragged:
+        lens = torch.tensor(sorted((1 + (7 * i) % T for i in range(B)), reverse=True), dtype=torch.int32).cuda()
+    outs = []
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv("TGRU_NO_STEP_FUSE", "1")
+        tg.reload_switches()
+        n0 = tg.launch_count()
+        outs.append(tg.gru_forward_backward_raw(x, ws, B, T, tg.LAYOUT_TBF, dy, h0=h0, lengths=lens))
+        outs[-1]["launches"] = tg.launch_count() - n0
+        torch.cuda.synchronize()
+    a, b = outs
+    assert a["launches"] == b["launches"] - L          # one projection GEMM per layer less
+    assert_close(a["y"].cpu().numpy(), b["y"].cpu().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
+    assert_close(a["h_n"].cpu().numpy(), b["h_n"].cpu().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "h_n")
+    assert_close(a["dx"].cpu().numpy(), b["dx"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    for i, (p, q) in enumerate(zip(a["grads"], b["grads"])):
+        assert_close(p.cpu().numpy(), q.cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"grad {i}")
+    assert tg.persist_timeouts() == 0
 
 
 def test_large_hidden_row_tiles_are_resident_per_xcd(monkeypatch):

@@ -276,11 +276,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, long by
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_opt(const void *p, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
 }
+#ifndef TGRU_STREAM_AUX
+#define TGRU_STREAM_AUX 0
+#endif
+// (cache policy of the once-touched streams -- input projections, saved gates, dy: 0 default, 2 non-temporal)
 __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, sbase, 0));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, sbase, TGRU_STREAM_AUX));
 }
 __device__ __forceinline__ void st1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, sbase, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, sbase, TGRU_STREAM_AUX);
 }
 __device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kAuxSc1);
@@ -1414,6 +1418,274 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_dma_kernel(Persi
 }
 
 
+
+// ----------------------------------------------------------------------------------------------
+// The loader-wave forward kernel WITH THE INPUT PROJECTION INSIDE.  Between the moment a workgroup has stored
+// its tile of h_t and the moment it may start on step t+1 lie the drain of its stores, the arrival, its
+// peers' arrivals and the first fetch of what they stored: about 9 us of the 31 a step takes, with the matrix
+// pipe idle.  The input projection of step t+1, x_{t+1} . W_ih^T for the same tile, depends on none of that
+// (the layer's input is complete before the launch), has the very shape of the recurrent product (128 rows x
+// 96 columns, k-tiles of W_ih in place of W_hh, rows of x in place of rows of h) and the same cost.  So it
+// runs right there: step t = recurrent product (r and z accumulate ON TOP of the projection's sums, the n gate
+// keeps the two parts apart) -> gates, state tile, stores -> first half of the projection of step t+1 -> the
+// stores have long drained: arrival -> second half of the projection, under which the peers' arrivals and
+// the hand-off disappear.  The batched input-projection GEMM of the layer and the (T*B, 3H) buffer it wrote
+// and the recurrent kernel read back are gone.  Needs the layer input time-major or batch-major with a width
+// that is a multiple of the k-tile.
+//
+// Loader waves and product waves walk ONE sequence of tiles -- P(0), then for every step R(t) [absent at t = 0
+// without an initial state], P(t+1) [absent after the last step] -- through the same ring; the two barriers of a
+// step that are not tile barriers (state tile in LDS; arrival) sit after R(t) and in the middle of P(t+1).  A
+// tile of R(t+1) may only be requested once this workgroup itself has arrived for step t (the loader polls for
+// ALL workgroups of the row tile, its own included), so the loader's run-ahead stops at that barrier and is
+// made up behind it.
+// ----------------------------------------------------------------------------------------------
+template <int BK>      // k-tile (32)
+__global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_fused_kernel(PersistFwd s) {
+    using namespace pd;
+    constexpr int BN = 3 * kUnits, Q = BK / 4, LDH = kUnits + 4;
+    constexpr int kSlots = kFwdSlots;
+    constexpr int kAhead = kSlots - 1, kFly = kAhead - 1;
+    constexpr int kATile = kRows * BK, kBTile = BN * BK, kSlot = kATile + kBTile;      // floats
+    constexpr int kRowsPerInst = 256 / BK;
+    constexpr int kAPer = kATile / 256 / kLoaders, kBPer = kBTile / 256 / kLoaders;
+    constexpr int kPerTile = kAPer + kBPer;
+    static_assert(kATile % (256 * kLoaders) == 0 && kBTile % (256 * kLoaders) == 0 && kFly * kPerTile < 64, "tile split");
+    static_assert(kFly == 2, "the vmcnt switch below is written for two younger tiles in flight");
+    __shared__ __attribute__((aligned(1024))) float lds[kSlots * kSlot + kRows * LDH];
+    float (*Hs)[LDH] = reinterpret_cast<float (*)[LDH]>(lds + kSlots * kSlot);
+    __shared__ int Ls[kRows];
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const FwdArgs &a = s.f;
+    const int H = a.H, B = a.B, T = a.T, In = a.In, NT = H / kUnits;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = mt * kRows, u0 = nt * kUnits;
+    unsigned *cnt = s.sync + 1 + mt;
+    const long step_bytes = (long)B * H * 4;
+    const int nR = H / BK, nP = In / BK, nP1 = nP / 2;      // tiles of a recurrent product / a projection (its first half)
+    const bool h0 = a.h0 != nullptr;
+    if (tid < kRows) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ---- loader waves ------------------------------------------------------------------------------
+        const int l = wave - 4;
+        const int x_bt = a.xmap.mode == 1;                     // layer input batch-major: row b*T + t
+        int va[kAPer], vx[kAPer], vb[kBPer], vi[kBPer];
+#pragma unroll
+        for (int i = 0; i < kAPer; ++i) {
+            const int r = (l * kAPer + i) * kRowsPerInst + lane / Q, p = lane % Q;
+            const int c = (p - r * Q / 16) & (Q - 1);
+            const int mc = min(m0 + r, B - 1);
+            va[i] = (mc * H + 4 * c) * 4;                                   // bytes inside one step's (B, H) block
+            vx[i] = ((x_bt ? mc * T : mc) * In + 4 * c) * 4;                // ... inside the input rows of one step
+        }
+#pragma unroll
+        for (int i = 0; i < kBPer; ++i) {
+            const int r = (l * kBPer + i) * kRowsPerInst + lane / Q, p = lane % Q;
+            const int c = (p - r * Q / 16) & (Q - 1);
+            vb[i] = (((r >> 5) * H + u0 + (r & 31)) * H + 4 * c) * 4;       // rows of W_hh: gate * H + unit
+            vi[i] = (((r >> 5) * H + u0 + (r & 31)) * In + 4 * c) * 4;      // rows of W_ih
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.w_hh, (long)3 * H * H * 4);
+        const __amdgpu_buffer_rsrc_t rs_wi = rsrc_of(a.w_ih, (long)3 * H * In * 4);
+        const long x_step = x_bt ? (long)In : (long)B * In;                 // floats from one step's input rows to the next
+        const long x_bytes = x_bt ? ((long)(B - 1) * T + 1) * In * 4 : (long)B * In * 4;
+        // the tile sequence as the requests walk it: (step, recurrent or projection, k-tile)
+        int it_t = 0, it_kt = 0;
+        bool it_rec = false;                                                 // starts with P(0)
+        int issued = 0, consumed = 0, arrived = -1;                          // arrived: last step this workgroup arrived for
+        bool more = true;
+        auto issue_one = [&]() -> bool {       // request the next tile of the sequence, unless it has to wait
+            if (!more) return false;
+            if (it_rec && it_t - 1 > arrived) return false;                 // R(t) needs this workgroup's arrival for t-1
+            float *slot = lds + (issued % kSlots) * kSlot;
+            if (it_rec) {
+                if (it_kt == 0 && it_t > 0) loader_wait_for_peers(cnt, (unsigned)(NT * it_t), s.err, s.spin_limit, lane);
+                const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(it_t > 0 ? s.ybuf + (long)(it_t - 1) * B * H : a.h0, step_bytes);
+#pragma unroll
+                for (int i = 0; i < kAPer; ++i) dma16(rs_h, slot + (l * kAPer + i) * 256, va[i], it_kt * BK * 4, 1);
+#pragma unroll
+                for (int i = 0; i < kBPer; ++i) dma16(rs_w, slot + kATile + (l * kBPer + i) * 256, vb[i], it_kt * BK * 4, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t rs_x = rsrc_of(a.x + it_t * x_step, x_bytes);
+#pragma unroll
+                for (int i = 0; i < kAPer; ++i) dma16(rs_x, slot + (l * kAPer + i) * 256, vx[i], it_kt * BK * 4, 0);
+#pragma unroll
+                for (int i = 0; i < kBPer; ++i) dma16(rs_wi, slot + kATile + (l * kBPer + i) * 256, vi[i], it_kt * BK * 4, 0);
+            }
+            ++issued;
+            // advance: P(t) -> R(t) [or straight to P(t+1) at t = 0 without an initial state] -> P(t+1) -> ...
+            if (++it_kt == (it_rec ? nR : nP)) {
+                it_kt = 0;
+                if (it_rec) {                      // R(t) done: P(t+1) follows unless t was the last step
+                    if (it_t + 1 < T) { it_rec = false; ++it_t; }
+                    else more = false;
+                } else if (it_t > 0 || h0) {       // P(t) done: R(t)
+                    it_rec = true;
+                } else if (T > 1) {                // P(0) without a state: gates of step 0 need no product, P(1) next
+                    it_t = 1;
+                } else {
+                    more = false;
+                }
+            }
+            return true;
+        };
+        auto consume = [&](int n) {             // the barriers of n tiles, each after its tile has landed
+            for (int i = 0; i < n; ++i) {
+                const int younger = issued - consumed - 1;
+                if (younger >= 2) wait_vmcnt<2 * kPerTile>();
+                else if (younger == 1) wait_vmcnt<kPerTile>();
+                else wait_vmcnt<0>();
+                lds_barrier();                   // tile `consumed` may be read; everybody is done with the one before
+                ++consumed;
+                while (issued < consumed + kAhead && issue_one()) {}
+            }
+        };
+        while (issued < kAhead && issue_one()) {}
+        consume(nP);                                                         // P(0)
+        for (int t = 0; t < T; ++t) {
+            if (t > 0 || h0) consume(nR);                                    // R(t)
+            lds_barrier();                                                   // (the product waves' state tile is in LDS)
+            if (t + 1 < T) consume(nP1);
+            lds_barrier();                                                   // (their stores are done: arrival)
+            arrived = t;
+            while (issued < consumed + kAhead && issue_one()) {}             // what had to wait for the arrival
+            if (t + 1 < T) consume(nP - nP1);
+        }
+        return;
+    }
+
+    // ---- product waves -----------------------------------------------------------------------------------
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int u = u0 + lrow;
+    const long plane = (long)T * B * H;
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) valid |= (m0 + 32 * wave + d_row(r, lk) < B ? 1u : 0u) << r;
+    int roff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wave + d_row(r, lk), B - 1) * H + u) * 4;
+    // r and z see the sum of both biases; the n gate keeps b_in with the projection and b_hn with the recurrent part
+    const float b_r = a.b_ih[u] + a.b_hh[u], b_z = a.b_ih[H + u] + a.b_hh[H + u];
+    const float b_nx = a.b_ih[2 * H + u], b_nh = a.b_hh[2 * H + u];
+    float hp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mc = min(m0 + 32 * wave + d_row(r, lk), B - 1);
+        hp[r] = a.h0 ? a.h0[(long)mc * H + u] : 0.f;
+    }
+    const int ma = 32 * wave + lrow;
+    const int fa = ma * BK, fb = kATile + lrow * BK;
+    int g = 0;                                   // tiles consumed so far: the ring slot of the next one
+    f32x16 acc_r, acc_z, acc_nx, acc_nh;
+    // one k-tile of a product: r and z always, the n part into `acc_n`
+    auto tile = [&](f32x16 &acc_n) {
+        lds_barrier();
+        const float *slot = lds + (g % kSlots) * kSlot;
+        ++g;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            const int c = 2 * q + lk;
+            const float4 av = *reinterpret_cast<const float4 *>(slot + fa + 4 * rot<BK>(c, ma));
+            const float *bp = slot + fb + 4 * rot<BK>(c, lrow);
+            const float4 b0 = *reinterpret_cast<const float4 *>(bp);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * BK);
+            const float4 b2 = *reinterpret_cast<const float4 *>(bp + 64 * BK);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b2.x, acc_n, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2.y, acc_n, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2.z, acc_n, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b2.w, acc_n, 0, 0, 0);
+        }
+    };
+    auto clear_projection = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_nx[r] = 0.f; }
+    };
+    clear_projection();
+    for (int kt = 0; kt < nP; ++kt) tile(acc_nx);                           // P(0)
+
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_nh[r] = 0.f;
+        if (t > 0 || h0)
+            for (int kt = 0; kt < nR; ++kt) tile(acc_nh);                   // R(t), on top of P(t) for r and z
+
+        float ynew[16];
+        {
+            float *gt = a.gates ? a.gates + (long)t * B * H : nullptr;      // (absent tensors: empty descriptors)
+            const __amdgpu_buffer_rsrc_t rs_r = rsrc_opt(gt, step_bytes), rs_z = rsrc_opt(gt ? gt + plane : nullptr, step_bytes),
+                                         rs_n = rsrc_opt(gt ? gt + 2 * plane : nullptr, step_bytes),
+                                         rs_h = rsrc_opt(gt ? gt + 3 * plane : nullptr, step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int len = Ls[32 * wave + d_row(r, lk)];      // 0 for rows past the batch
+                const bool active = t < len;
+                const float ghn = acc_nh[r] + b_nh;
+                const float rg = fast_sigmoid(acc_r[r] + b_r);
+                const float zg = fast_sigmoid(acc_z[r] + b_z);
+                const float ng = fast_tanh(acc_nx[r] + b_nx + rg * ghn);
+                const float hnew = (1.f - zg) * ng + zg * hp[r];
+                const float yv = active ? hnew : 0.f;
+                hp[r] = yv;
+                ynew[r] = yv;
+                Hs[32 * wave + d_row(r, lk)][lrow] = yv;
+                const int og = active ? roff[r] : 0x7fffffff;       // an offset beyond the block drops a lane's store
+                st1(rs_r, og, 0, rg); st1(rs_z, og, 0, zg); st1(rs_n, og, 0, ng); st1(rs_h, og, 0, ghn);
+            }
+        }
+        lds_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(s.ybuf + (long)t * B * H, step_bytes);
+#pragma unroll
+            for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
+                const int slot = tid + p * 256, row = slot >> 3, c4 = (slot & 7) << 2;
+                const float4 v = *reinterpret_cast<const float4 *>(&Hs[row][c4]);
+                const int off = m0 + row < B ? ((m0 + row) * H + u0 + c4) * 4 : 0x7fffffff;
+                st4_sc1(rs_y, off, v);
+            }
+        }
+        // the caller's y (when it is not the exchange buffer) and h_n: nobody waits for these
+        if (a.y_ext && a.y_ext != s.ybuf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + d_row(r, lk);
+                const long er = ((valid >> r) & 1) ? map_tb(a.ymap, t, m) : -1L;
+                if (er >= 0) a.y_ext[er * H + u] = ynew[r];
+            }
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs_hn = rsrc_opt(a.h_n, step_bytes);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st1(rs_hn, t == Ls[32 * wave + d_row(r, lk)] - 1 ? roff[r] : 0x7fffffff, 0, ynew[r]);
+        }
+        const bool next = t + 1 < T;
+        if (next) {
+            clear_projection();
+            for (int kt = 0; kt < nP1; ++kt) tile(acc_nx);                  // first half of P(t+1)
+        }
+        // every store of this workgroup issued so far is complete (they had half a projection to drain); then
+        // one lane tells the row tile's counter (the barrier also keeps Hs from being rewritten too early)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (next && tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (next)
+            for (int kt = nP1; kt < nP; ++kt) tile(acc_nx);                 // second half, covering the hand-off
+    }
+}
+
 }  // namespace
 
 // (32-bit element offsets inside one step's rows: B * 4H must stay below 2^31)
@@ -1455,6 +1727,17 @@ size_t gru_step_sync_words(int B) { return 1 + 2 * (size_t)((B + kRows - 1) / kR
 static bool persist_ok(int B, int H, const unsigned *sync) {
     return sync && !switches().no_persist && persist_row_tiles(H / kUnits) > 0 && (long)B * 4 * H * 4 < (1L << 31);
 }
+// The forward kernel with the input projection inside: layer input time-major or batch-major (32-bit byte offsets
+// inside one step's rows), a width that is a multiple of the k-tile, everything 16-byte aligned.
+bool gru_step_fwd_fuses(const FwdArgs &a) {
+    if (switches().no_step_fuse || switches().no_step_dma || !a.x || !a.w_ih || !a.b_ih) return false;
+    if (!gru_step_persistent(a.B, a.H) || a.H % pd::kFwdBK != 0 || a.In % pd::kFwdBK != 0) return false;
+    if (a.xmap.mode != 0 && a.xmap.mode != 1) return false;
+    if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.w_ih)) & 15) return false;
+    const long x_bytes = a.xmap.mode == 1 ? ((long)(a.B - 1) * a.T + 1) * a.In * 4 : (long)a.B * a.In * 4;
+    return x_bytes < (1L << 31) && (long)3 * a.H * a.In * 4 < (1L << 31);
+}
+
 bool gru_step_persistent(int B, int H) {
     return gru_step_supported(B, H) && !switches().no_persist && persist_row_tiles(H / kUnits) > 0 &&
            (long)B * 4 * H * 4 < (1L << 31);
@@ -1549,7 +1832,8 @@ hipError_t launch_gru_step_fwd(const FwdArgs &a, unsigned *sync, unsigned *err, 
             k.MT = min(per_launch, MT - mt0);
             k.mtx = (k.MT + 7) / 8;
             k.spin_limit = switches().spin_limit;
-            if (!switches().no_step_dma && a.H % pd::kFwdBK == 0) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<pd::kFwdBK>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
+            if (gru_step_fwd_fuses(a)) TGRU_LAUNCH(gru_persist_fwd_fused_kernel<pd::kFwdBK>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
+            else if (!switches().no_step_dma && a.H % pd::kFwdBK == 0) TGRU_LAUNCH(gru_persist_fwd_dma_kernel<pd::kFwdBK>, dim3(8 * k.mtx * NT), dim3(pd::kThreads), 0, s, k);
             else if (a.H % kPersistBK == 0) TGRU_LAUNCH(gru_persist_fwd_kernel<kPersistBK>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
             else TGRU_LAUNCH(gru_persist_fwd_kernel<32>, dim3(8 * k.mtx * NT), dim3(256), 0, s, k);
         }

@@ -20,6 +20,7 @@ void Switches::read() {
     no_step = on("TGRU_NO_STEP");
     no_persist = on("TGRU_NO_PERSIST");
     no_step_dma = on("TGRU_NO_STEP_DMA");
+    no_step_fuse = on("TGRU_NO_STEP_FUSE");
     step_bwd_wide = on("TGRU_STEP_BWD_WIDE");
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
@@ -87,6 +88,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_STEP=1        persistent 16-sequence kernels instead of one launch per step (gru_step.hip)
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
+//   TGRU_NO_STEP_FUSE=1   H > 128: the layer's input projection as a batched GEMM instead of inside the forward kernel
 //   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
 //   TGRU_SPIN_LIMIT=n     H > 128: polls after which a wait of a persistent kernel gives up (default 2^24)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
@@ -413,7 +415,9 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.gi = gi; f.wp = wp; f.w_hh = w_hh[l]; f.b_hh = b_hh[l];
         f.x = in; f.xmap = l == 0 ? ext_map(d, toff) : id_map(d); f.In = In_l; f.w_ih = w_ih[l]; f.b_ih = b_ih[l];
         f.B = B; f.T = T; f.H = H;
-        const bool fused = mid && !stepk && gru_mid96_fwd_supported(f);    // that kernel computes gi itself
+        // kernels that compute gi themselves: the H = 96 kernel, and the persistent H > 128 kernel where it can
+        const bool step_fused = stepk && err && gru_step_fwd_fuses(f);
+        const bool fused = (mid && !stepk && gru_mid96_fwd_supported(f)) || step_fused;
         if (!fused) {
             GemmArgs g{};
             g.A = in; g.lda = In_l; g.Bm = w_ih[l]; g.ldb = In_l; g.C = gi; g.ldc = 3 * H; g.bias = b_ih[l];
@@ -440,7 +444,7 @@ int tgru_forward(const float *x, const float *h0, const int32_t *lengths, const 
         f.B = B; f.T = T; f.H = H;
         // (the packed-W_hh region of the workspace is free on this path: it holds the sync words)
         if (stepk) TGRU_HIP(launch_gru_step_fwd(f, reinterpret_cast<unsigned *>(wp), err, s));
-        else if (fused) TGRU_HIP(launch_gru_mid96_fwd(f, s));
+        else if (fused && !step_fused) TGRU_HIP(launch_gru_mid96_fwd(f, s));
         else if (mid) TGRU_HIP(launch_gru_mid_fwd(f, s));
         else TGRU_HIP(launch_gru_fwd(f, s));
         in = f.y_int;
