@@ -401,6 +401,18 @@ int tgru_loss_final(int kind, int B, int T, int H, int F, float gamma, float *bu
 int tgru_loss_backward(int kind, const float *const *in, float *const *din, const float *const *dout,
                        int B, int T, int H, int F, float gamma, const float *buf, tgru_stream_t stream);
 
+/*
+ * Uniform noise in [0, 1) with 24 random bits per float, the distribution of the `torch.rand_like(x)` the joint
+ * phase draws (outdated_files/TimeGANv1.py:762,793), from a counter-based generator: out[i] is element
+ * first + i of noise stream `stream` under `seed`, a pure function of those three numbers (Philox4x32-10:
+ * counter = {element / 4, stream}, key = seed, word element % 4, (word >> 8) * 2^-24).  A data-parallel rank that
+ * owns rows [lo, hi) of a global batch therefore draws exactly its rows (first = lo * row width), and all ranks
+ * together draw the tensor one process would draw.  Replaces the draw only; the reference's own generator
+ * (torch's, whose streams depend on the device and the launch shape) is not reproduced.
+ */
+int tgru_uniform(float *out, long n, unsigned long long seed, unsigned long long stream,
+                 unsigned long long first, tgru_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

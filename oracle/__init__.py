@@ -20,7 +20,7 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a checker build, not a product build)."""
-    src = [os.path.join(_HERE, f) for f in ("gru_oracle.c", "gru_oracle_impl.h")]
+    src = [os.path.join(_HERE, f) for f in ("gru_oracle.c", "gru_oracle_impl.h", "philox_oracle.c")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
     if stale:
@@ -38,6 +38,10 @@ def _load():
             fn = getattr(lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5
+        lib.philox4x32_10.restype = None
+        lib.philox4x32_10.argtypes = [ctypes.c_void_p] * 3
+        lib.philox_uniform_f32.restype = None
+        lib.philox_uniform_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
         lib.gru_oracle_param_count.restype = ctypes.c_int64
         lib.gru_oracle_param_count.argtypes = [ctypes.c_int] * 3
         _lib = lib
@@ -107,4 +111,20 @@ def gru(x, weights, lengths=None, dy=None, dhn=None, dtype=np.float32):
     if dy is not None:
         out["dx"] = dx
         out["grads"] = unflatten_params(grads, In, H, L)
+    return out
+
+
+def philox4x32_10(ctr, key):
+    """One Philox4x32-10 block: four 32-bit counter words, two key words -> four output words."""
+    c = np.asarray(ctr, dtype=np.uint32).copy()
+    k = np.asarray(key, dtype=np.uint32).copy()
+    out = np.zeros(4, dtype=np.uint32)
+    _load().philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def uniform(n, seed, stream, first=0):
+    """Elements [first, first + n) of noise stream `stream` under `seed`, as tgru_uniform defines them."""
+    out = np.empty(int(n), dtype=np.float32)
+    _load().philox_uniform_f32(out.ctypes.data, int(n), int(seed), int(stream), int(first))
     return out

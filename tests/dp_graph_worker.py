@@ -48,6 +48,18 @@ def main():
                     f"{name}: {net}.{k} differs, max {float((w - v).abs().max()):.3e}"
         print(name, "ok", flush=True)
 
+    # the data-parallel gradient exchange is in place: every gradient of a step is a view of its optimiser group's
+    # arena, which is what gets all-reduced (nothing is concatenated or copied back)
+    parallel.FORCE_COLLECTIVES = True
+    tr = tg.TimeGANTrainer(cfg, device=dev, group=dist.group.WORLD)
+    tr.joint_step(x, noise=noise[0])
+    tr.embedding_step(x)
+    arena = tr._arenas[("emb", "rec")]
+    grads = [p.grad for k in ("emb", "rec") for p in tr.nets[k].parameters()]
+    assert arena.n > 0 and all(g is not None and arena.owns(g) for g in grads)
+    assert set(tr._arenas) >= {("g", "sup"), ("emb", "rec")}
+    print("arena ok", flush=True)
+
     # generation + post-hoc scores: the sharded code path (all-gather, sharded minibatches, all-reduced
     # gradients and counts over RCCL) against the plain one
     import numpy as np

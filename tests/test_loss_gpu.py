@@ -2,6 +2,7 @@
 (the loss builders of outdated_files/TimeGANv1.py:410-553), values and gradients, on the GPU."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -129,3 +130,39 @@ def test_rank_shards_sum_to_whole_batch():
     for i, q in enumerate(req):
         if q:
             _close(torch.cat([grads[0][i], grads[1][i]]), whole[i].grad, GRAD_RTOL, f"sharded grad[{i}]")
+
+
+@pytest.mark.parametrize("n,first", [(1, 0), (7, 3), (4096, 0), (100003, 5), (24 * 6 * 300, 24 * 6 * 129)])
+def test_counter_noise_is_bit_exact_and_shards_are_slices(n, first):
+    """tgru_uniform against the CPU restatement (pinned by Philox's published known answers), bit for bit, at
+    aligned and unaligned starts; a rank's rows are the slice of the tensor one process draws."""
+    import oracle
+    from timegan_amd.functional import uniform_
+    seed, stream = 0x1234567890ABCDEF, 42
+    out = torch.full((n + 8,), -1.0, device="cuda:0")
+    uniform_(out[4:4 + n], seed, stream, first)
+    got = out.cpu().numpy()
+    assert (got[:4] == -1).all() and (got[4 + n:] == -1).all()          # nothing written outside the range
+    assert np.array_equal(got[4:4 + n], oracle.uniform(n, seed, stream, first))
+    odd = torch.empty(n + 1, device="cuda:0")[1:]                          # a start that is not 16-byte aligned
+    uniform_(odd, seed, stream, first)
+    assert np.array_equal(odd.cpu().numpy(), got[4:4 + n])
+
+
+def test_trainer_noise_of_a_shard_is_the_slice_of_the_global_batch():
+    """Two 'ranks' with shards of 5 and 3 rows of a batch of 8 draw, with the same seed, exactly the rows a single
+    process draws for the whole batch (counter-based noise; here the ranks are played in one process)."""
+    import timegan_amd as tg
+    cfg = tg.make_cfg(features=5, hidden=12, layers=1, seq_len=6, device="cuda:0")
+    x = torch.rand(8, 6, 5, device="cuda:0")
+    torch.manual_seed(4)
+    whole = tg.TimeGANTrainer(cfg, device="cuda:0", counter_noise=True)
+    z = torch.stack(whole._noise_like(x, 3))
+    assert float(z.min()) >= 0 and float(z.max()) < 1 and not torch.equal(z[0], z[1])
+    parts = []
+    for lo, hi in ((0, 5), (5, 8)):
+        torch.manual_seed(4)
+        tr = tg.TimeGANTrainer(cfg, device="cuda:0", counter_noise=True)
+        tr._extent = (lo, hi, 8)
+        parts.append(torch.stack(tr._noise_like(x[lo:hi], 3)))
+    assert torch.equal(torch.cat(parts, dim=1), z)

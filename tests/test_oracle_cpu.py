@@ -45,3 +45,21 @@ def test_oracle_rejects_bad_lengths():
         oracle.gru(case["x"], case["weights"], [2, 5, 7])
     with pytest.raises(RuntimeError, match="greater than 0"):
         oracle.gru(case["x"], case["weights"], [7, 5, 0])
+
+
+def test_philox_oracle_reproduces_the_published_known_answers():
+    """Philox4x32-10 known-answer vectors of the Random123 library (kat_vectors: counter, key -> output), which
+    pin the CPU restatement of the library's noise generator; then the float mapping: 24 bits, [0, 1)."""
+    import oracle
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(v) for v in oracle.philox4x32_10(ctr, key)] == want
+    u = oracle.uniform(4, 0, 0)
+    assert [float(v) for v in u] == [(w >> 8) / 2.0 ** 24 for w in kat[0][2]]
+    big = oracle.uniform(100000, 7, 3)
+    assert big.min() >= 0.0 and big.max() < 1.0 and abs(float(big.mean()) - 0.5) < 0.01
+    # a shard of a stream is the slice of the whole stream, wherever it starts
+    assert np.array_equal(oracle.uniform(1000, 7, 3, first=4321), oracle.uniform(6000, 7, 3)[4321:5321])

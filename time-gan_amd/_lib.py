@@ -98,6 +98,7 @@ SIGNATURES = {
     "tgru_head_reduce_jobs": (_i, [ctypes.POINTER(HeadArgs), ctypes.POINTER(ReduceJob), _i]),
     "tgru_reduce_jobs": (_i, [ctypes.POINTER(ReduceJob), _i, _vp]),
     "tgru_adam_jobs": (_i, [ctypes.POINTER(AdamJob), _i] + [ctypes.c_float] * 4 + [_vp, _vp]),
+    "tgru_uniform": (_i, [_vp, ctypes.c_long, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp]),
     "tgru_loss_layout": (_i, [_i] * 3 + [ctypes.POINTER(ctypes.c_int64)]),
     "tgru_loss_partial": (_i, [_i, _i, _vp] + [_i] * 4 + [_vp, _vp]),
     "tgru_loss_final": (_i, [_i] * 5 + [ctypes.c_float, _vp, _vp]),

@@ -62,14 +62,17 @@ class ResidentDataset:
         return int(self.data.shape[0])
 
     def batches(self, batch_size: int, shuffle: bool = True, generator: Optional[torch.Generator] = None,
-                rank: int = 0, world: int = 1) -> Iterator[torch.Tensor]:
+                rank: int = 0, world: int = 1, with_extent: bool = False) -> Iterator[torch.Tensor]:
         """Batches of one epoch; with `world` > 1 every rank takes its contiguous shard of each global
-        batch (the same permutation must be drawn on every rank: pass identically seeded generators)."""
+        batch (the same permutation must be drawn on every rank: pass identically seeded generators).
+        `with_extent`: yield (batch, (start, stop, rows of the global batch)) -- where the shard sits in its
+        global batch, known here by arithmetic."""
         n = len(self)
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         order = order.to(self.data.device)
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
+            extent = (0, int(idx.numel()), int(idx.numel()))
             if world > 1:
                 # shard sizes differ by at most one (parallel.shard_batch); a tail batch with fewer rows than
                 # ranks is dropped by EVERY rank, so that all ranks run the same number of steps
@@ -77,6 +80,8 @@ class ResidentDataset:
                     continue
                 base, rem = divmod(idx.numel(), world)
                 start = rank * base + min(rank, rem)
-                idx = idx[start:start + base + (1 if rank < rem else 0)]
+                extent = (start, start + base + (1 if rank < rem else 0), int(idx.numel()))
+                idx = idx[start:extent[1]]
             if idx.numel():
-                yield self.data.index_select(0, idx)
+                x = self.data.index_select(0, idx)
+                yield (x, extent) if with_extent else x

@@ -25,11 +25,46 @@ _active = None
 _CAPACITY = 512     # jobs a queue can hold before it has to flush on its own
 
 
+class GradArena:
+    """One flat device buffer that the backward functions of a pass carve their parameter-gradient buffers from
+    (a bump allocator, 16-byte granules).  A data-parallel trainer keeps one per optimiser group and passes it to
+    `deferred_reductions(arena=...)`: every parameter's FIRST gradient of the pass -- the tensor autograd stores as
+    `.grad` without copying -- is then a view of this buffer, later gradients of the same parameter are added into
+    it in place, and the group's gradient exchange is ONE in-place all-reduce of `used()` with nothing to
+    concatenate or copy back (`parallel.all_reduce_grads`).  The buffer is reused by the next pass: gradients of
+    an earlier pass that nobody has zeroed are overwritten, which is when the reference zeroes them anyway
+    (outdated_files/TimeGANv1.py:765-769)."""
+
+    def __init__(self, capacity: int, device):
+        self.buf = torch.empty(max(int(capacity), 4), device=device, dtype=torch.float32)
+        self.n = 0
+
+    def reset(self):
+        self.n = 0
+
+    def take(self, count: int):
+        """`count` floats of the arena, or None when it is full (the caller allocates as usual)."""
+        end = self.n + (count + 3) // 4 * 4
+        if end > self.buf.numel():
+            return None
+        out = self.buf[self.n:self.n + count]
+        self.n = end
+        return out
+
+    def used(self) -> torch.Tensor:
+        return self.buf[:self.n]
+
+    def owns(self, t: torch.Tensor) -> bool:
+        lo = self.buf.data_ptr()
+        return t.is_contiguous() and lo <= t.data_ptr() and t.data_ptr() + 4 * t.numel() <= lo + 4 * self.n
+
+
 class _Queue:
     """The owed reductions of one backward pass.  The library writes the jobs of each call straight into
     one preallocated job array (no Python object per job)."""
 
-    def __init__(self):
+    def __init__(self, arena=None):
+        self.arena = arena        # GradArena the pass's first gradients are carved from, or None
         self.jobs = (ReduceJob * _CAPACITY)()
         self.count = 0
         self.keep, self.device = [], None
@@ -53,6 +88,12 @@ class _Queue:
             self.flush()
             return False
         return first
+
+    def grad_buffer(self, count: int, device) -> torch.Tensor:
+        """Flat buffer for the gradients a backward call is about to return for parameters that receive their
+        first gradient of the pass (may_defer() said so): from the arena when there is one with room."""
+        buf = self.arena.take(count) if (self.arena is not None and self.arena.buf.device == device) else None
+        return buf if buf is not None else torch.empty(count, device=device, dtype=torch.float32)
 
     def add(self, fn, args_struct, keep, weights, device):
         """Queue what the deferred backward call described by `args_struct` still owes
@@ -82,12 +123,15 @@ def active():
 
 
 @contextmanager
-def deferred_reductions():
+def deferred_reductions(arena=None):
+    """`arena` (a GradArena, reset here): where this pass's first parameter gradients are placed."""
     global _active
     if _active is not None:          # nested: the outer block owns the queue
         yield _active
         return
-    q = _Queue()
+    if arena is not None:
+        arena.reset()
+    q = _Queue(arena)
     _active = q
     try:
         yield q

@@ -21,17 +21,20 @@ def _addr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _alloc_grads(weights: Sequence[torch.Tensor]):
+def _alloc_grads(weights: Sequence[torch.Tensor], queue=None):
     """One flat buffer for the gradients of `weights` and a view of it per weight.  Autograd receives the
     views (no one else references them, so AccumulateGrad adopts them without copying -- a copy taken
     before a deferred reduction has run would copy nothing useful); whoever must keep the memory alive
-    holds the flat buffer."""
-    flat = torch.empty(sum(w.numel() for w in weights), device=weights[0].device, dtype=torch.float32)
-    views, o = [], 0
+    holds the flat buffer.  `queue`: the pass's deferred-reduction queue when these are the weights' first
+    gradients of the pass; the buffer then comes from the queue's gradient arena, if it has one.  Every view
+    starts on a 16-byte boundary."""
+    offs, n = [], 0
     for w in weights:
-        views.append(flat[o:o + w.numel()].view(w.shape))
-        o += w.numel()
-    return flat, views
+        offs.append(n)
+        n += (w.numel() + 3) // 4 * 4
+    dev = weights[0].device
+    flat = queue.grad_buffer(n, dev) if queue is not None else torch.empty(n, device=dev, dtype=torch.float32)
+    return flat, [flat[o:o + w.numel()].view(w.shape) for o, w in zip(offs, weights)]
 
 
 def _ptr_array(ts: Sequence[torch.Tensor]):
@@ -135,13 +138,13 @@ class _GRUFunction(torch.autograd.Function):
             # no weight of this call wants a gradient (a network the step does not update): the library is
             # told so (NULL gradient arrays) and forms dx / dh0 only
             want_w = any(ctx.needs_input_grad[8:])
-            flat, grads = _alloc_grads(weights) if want_w else (None, [None] * len(weights))
+            queue = deferred.active()
+            defer = want_w and queue is not None and queue.may_defer(weights)
+            flat, grads = _alloc_grads(weights, queue if defer else None) if want_w else (None, [None] * len(weights))
             arrays = [_ptr_array(g) for g in _split_weights(weights, L)]
             if want_w:
                 arrays += [_ptr_array(g) for g in _split_weights(grads, L)]
             cast = [ctypes.cast(a, ctypes.c_void_p) for a in arrays] + ([] if want_w else [None] * 4)
-            queue = deferred.active()
-            defer = want_w and queue is not None and queue.may_defer(weights)
             args = BackwardArgs(_addr(dy), _addr(dh_n), _addr(x), _addr(h0), _addr(y), _addr(lengths), _addr(toff),
                                 *cast[:4], _addr(reserve), _addr(ws), _addr(dx), _addr(dh0), *cast[4:],
                                 B, T, In, H, L, layout, _lib.DEFER_REDUCE if defer else 0)
@@ -242,7 +245,7 @@ class _GRUPairFunction(torch.autograd.Function):
                                  dtype=torch.float32)
                 dx = torch.empty_like(x) if ctx.needs_input_grad[base] else None
                 dh0 = torch.empty_like(h0) if (has_h0 and ctx.needs_input_grad[base + 1]) else None
-                flat, grads = _alloc_grads(weights) if want_w[k] else (None, [None] * nw)
+                flat, grads = _alloc_grads(weights, queue if defer else None) if want_w[k] else (None, [None] * nw)
                 arrays = [_ptr_array(g) for g in _split_weights(weights, L)]
                 if want_w[k]:
                     arrays += [_ptr_array(g) for g in _split_weights(grads, L)]
@@ -328,6 +331,18 @@ def gru_forward_backward_raw(x, weights, B, T, layout, dy, h0=None, dh_n=None, l
                                _ptr_array(gw_ih), _ptr_array(gw_hh), _ptr_array(gb_ih), _ptr_array(gb_hh),
                                B, T, In, H, L, layout, 0, s), "tgru_backward")
     return {"y": y, "h_n": h_n, "dx": dx, "dh0": dh0, "grads": grads}
+
+
+def uniform_(out: torch.Tensor, seed: int, stream: int, first: int = 0) -> torch.Tensor:
+    """Fills the dense fp32 GPU tensor `out` with elements [first, first + out.numel()) of noise stream `stream`
+    under `seed`, U[0, 1) (tgru_uniform of include/tgru.h: a pure function of (seed, stream, element), so shards of
+    one tensor can be drawn independently)."""
+    _require_gpu(out, "out")
+    assert out.is_contiguous()
+    with on_device(out.device):
+        check(lib().tgru_uniform(_ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1),
+                                 int(first), _stream(out.device)), "tgru_uniform")
+    return out
 
 
 def input_projection(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

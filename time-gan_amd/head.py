@@ -63,13 +63,16 @@ class _HeadFunction(torch.autograd.Function):
             n = lb.tgru_head_grad_floats(din, dmid, dout)
             # no parameter wants a gradient (a network the step does not update): dx only
             want_p = any(ctx.needs_input_grad[2:])
-            dparams = torch.empty(n, device=dev, dtype=torch.float32) if want_p else None
-            ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
-                             dtype=torch.float32)
-            dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
             live = [p for p in params if p is not None]
             queue = deferred.active()
             defer = want_p and queue is not None and queue.may_defer(live)
+            # (first gradients of the pass: from the pass's gradient arena when it has one)
+            dparams = None
+            if want_p:
+                dparams = queue.grad_buffer(n, dev) if defer else torch.empty(n, device=dev, dtype=torch.float32)
+            ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
+                             dtype=torch.float32)
+            dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
             flag = _lib.DEFER_REDUCE if defer else 0
             check(lb.tgru_head_backward(_ptr(x2), _ptr(dy2), _ptr(dx), M, din, dmid, dout,
                                         *[_ptr(p) for p in params], eps, _ptr(dparams), _ptr(ws), flag,
@@ -315,8 +318,10 @@ class _HeadPairFunction(torch.autograd.Function):
                 M, din, dmid, dout, eps = ctx.dims[k]
                 x2, params = heads[k]
                 dy2 = dy.contiguous().view(-1, dout)
-                dparams = torch.empty(lb.tgru_head_grad_floats(din, dmid, dout), device=dev,
-                                      dtype=torch.float32) if want_p[k] else None
+                dparams = None
+                if want_p[k]:
+                    nfl = lb.tgru_head_grad_floats(din, dmid, dout)
+                    dparams = queue.grad_buffer(nfl, dev) if defer else torch.empty(nfl, device=dev, dtype=torch.float32)
                 ws = torch.empty(lb.tgru_head_backward_workspace_bytes(M, din, dmid, dout) // 4, device=dev,
                                  dtype=torch.float32)
                 dx = torch.empty_like(x2) if ctx.needs_input_grad[2 + 9 * k] else None

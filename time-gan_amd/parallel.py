@@ -72,13 +72,25 @@ def dist_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     return _DistSum.apply(x, group)
 
 
-def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
-    """Sum the gradients of `modules` over all ranks through ONE flat bucket.  Returns bucket size."""
+def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None, arena=None) -> int:
+    """Sum the gradients of `modules` over all ranks.  Returns the number of floats exchanged.
+    With `arena` (the deferred.GradArena the backward pass carved its gradient buffers from) the gradients that
+    live in it -- on the GPU path all of them -- are summed by ONE in-place collective over the arena's used
+    part: nothing is concatenated or copied back.  Gradients outside it (torch's own backward functions) go
+    through one flat bucket: cat -> all-reduce -> one multi-tensor copy back."""
     if not multi_rank(group):
         return 0
     params = [p for m in modules for p in m.parameters() if p.grad is not None]
     if not params:
         return 0
+    count = 0
+    if arena is not None and arena.n > 0 and any(arena.owns(p.grad) for p in params):
+        flat = arena.used()
+        _all_reduce_sum(flat, group)
+        count += int(flat.numel())
+        params = [p for p in params if not arena.owns(p.grad)]
+        if not params:
+            return count
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     _all_reduce_sum(flat, group)
     views, off = [], 0
@@ -87,7 +99,7 @@ def all_reduce_grads(modules: Iterable[torch.nn.Module], group=None) -> int:
         views.append(flat[off:off + n].view_as(p.grad))
         off += n
     torch._foreach_copy_([p.grad for p in params], views)    # one multi-tensor copy, not one per parameter
-    return int(flat.numel())
+    return count + int(flat.numel())
 
 
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None) -> None:
@@ -131,6 +143,22 @@ def shard_bounds(n: int, group=None):
     base, rem = divmod(n, w)
     start = r * base + min(r, rem)
     return start, start + base + (1 if r < rem else 0)
+
+
+def broadcast_int(value: int, device, src: int = 0, group=None) -> int:
+    """`value` of rank `src` on every rank (a seed all ranks must share)."""
+    if not multi_rank(group):
+        return int(value)
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def equal_shard_extent(n_local: int, group=None):
+    """(start, stop, total) of this rank's rows when every rank holds n_local rows: no communication."""
+    w, r = world_size(group), rank(group)
+    return r * n_local, (r + 1) * n_local, w * n_local
 
 
 def shard_extent(n_local: int, device, group=None):

@@ -13,13 +13,13 @@ import torch
 from torch.optim import Adam
 
 from . import losses
-from .deferred import deferred_reductions
+from .deferred import GradArena, deferred_reductions
 from .modules import build_networks
 from .optim import AdamStep, init_adam_state
 import torch.distributed as dist
 
-from .parallel import (all_gather_rows, all_reduce_grads, broadcast_parameters, multi_rank, shard_batch,
-                       shard_extent)
+from .parallel import (all_gather_rows, all_reduce_grads, broadcast_int, broadcast_parameters, equal_shard_extent,
+                       multi_rank, shard_batch)
 
 
 class _GraphedStep:
@@ -60,10 +60,14 @@ class TimeGANTrainer:
     """
 
     def __init__(self, cfg: Dict, device=None, rnn_cls=None, group=None, nets=None, use_graphs: bool = False,
-                 all_gradients: bool = False):
+                 all_gradients: bool = False, counter_noise: Optional[bool] = None):
         """`all_gradients`: also form the gradients of the networks a sub-step runs through but does not
         update, as the reference does before it zeroes them unseen (see `_frozen`); same parameter updates,
-        more work -- for loops that want to look at those gradients."""
+        more work -- for loops that want to look at those gradients.
+        `counter_noise`: draw the joint phase's noise from the library's counter-based generator (see
+        `_noise_like`) instead of torch's; default: with several ranks, where it lets every rank draw just its
+        shard's rows of the global batch's noise.  True in a single process gives that process the very noise a
+        data-parallel run of the same seed uses."""
         self.cfg = cfg
         self.all_gradients = bool(all_gradients)
         self.device = torch.device(device if device is not None else cfg["system"]["device"])
@@ -73,6 +77,11 @@ class TimeGANTrainer:
             self.nets[k] = self.nets[k].to(self.device)
         self.group = group
         self._params = {}
+        self._arenas = {}              # per optimiser group: the arena its gradients live in (several ranks only)
+        self.counter_noise = multi_rank(group) if counter_noise is None else bool(counter_noise)
+        self._noise_seed = None        # seed of the counter-based noise, drawn at its first use
+        self._noise_draws = 0          # noise tensors drawn so far: the stream number of the next one
+        self._extent = None            # (start, stop, total rows) of the current shard, when fit() knows it
         broadcast_parameters(self.nets.values(), group=group)
         lr = float(cfg["system"]["lr"])
         n = self.nets
@@ -179,21 +188,58 @@ class TimeGANTrainer:
             for opt in self.opt.values():
                 opt.state.clear()
 
-    def _sync_grads(self, *names):
-        all_reduce_grads([self.nets[k] for k in names], group=self.group)
+    def _pass(self, *names):
+        """Context of one backward pass whose gradients for the networks `names` are exchanged afterwards: the
+        partial-gradient reductions of the pass are deferred into one launch, and with several ranks the pass's
+        gradient buffers come from one arena per optimiser group, which `_sync_grads` all-reduces in place."""
+        arena = None
+        if multi_rank(self.group) and self.device.type == "cuda":
+            arena = self._arenas.get(names)
+            if arena is None:
+                # room for every gradient of the group twice over: the head kernels' gradient blocks also hold
+                # the slots of stages a head does not have, and every view starts on a 16-byte boundary
+                n = sum(p.numel() + 64 for k in names for p in self.nets[k].parameters())
+                arena = self._arenas[names] = GradArena(2 * n, self.device)
+        return deferred_reductions(arena)
 
-    def _noise_like(self, x: torch.Tensor, count: int) -> List[torch.Tensor]:
+    def _sync_grads(self, *names):
+        all_reduce_grads([self.nets[k] for k in names], group=self.group, arena=self._arenas.get(names))
+
+    def _noise_like(self, x: torch.Tensor, count: int, out: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         """`count` noise tensors shaped like x, U[0,1) as torch.rand_like(x) draws them
-        (TimeGANv1.py:762,793).  With several ranks, x is this rank's shard of a global batch: every rank
-        draws the noise of the WHOLE batch from its (identically seeded) generator and keeps the rows of its
-        shard, so the ranks use different rows of one stream -- the rows a single process would have drawn
-        for the concatenated batch.  (Identically seeded ranks drawing rand_like(shard) would all get the
-        same rows: a generated batch of duplicates, whose batch statistics degenerate.)"""
-        if not multi_rank(self.group):
+        (TimeGANv1.py:762,793); into the rows of `out` (count, *x.shape) when given.  With several ranks, x is this
+        rank's shard of a global batch and the ranks must use different rows of ONE stream -- the rows a single
+        process would draw for the concatenated batch (identically seeded ranks drawing rand_like(shard) would all
+        get the same rows: a generated batch of duplicates, whose batch statistics degenerate).  On the GPU the
+        library's counter-based generator draws exactly the shard's rows (element = global row x row width +
+        offset, one stream per noise tensor); on the CPU every rank draws the whole batch from its identically
+        seeded torch generator and keeps its rows.  Where the shard sits comes from `fit` (arithmetic on the
+        global batch); a direct caller's shards are taken to be equal unless it sets `self._extent`."""
+        if not self.counter_noise and not multi_rank(self.group):
+            if out is not None:
+                out.uniform_()
+                return list(out)
             return [torch.rand_like(x) for _ in range(count)]
-        lo, hi, total = shard_extent(int(x.shape[0]), x.device, self.group)
+        lo, hi, total = self._extent if self._extent is not None else equal_shard_extent(int(x.shape[0]), self.group)
+        assert hi - lo == x.shape[0], "the shard extent does not match the batch"
+        if x.is_cuda and self.counter_noise:
+            from .functional import uniform_
+            buf = out if out is not None else torch.empty((count,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+            row = x[0].numel()
+            if self._noise_seed is None:
+                # from torch's generator (so torch.manual_seed governs it); every rank uses rank 0's
+                self._noise_seed = broadcast_int(int(torch.randint(0, 2 ** 62, (1,)).item()), self.device, group=self.group)
+            for i in range(count):
+                uniform_(buf[i], self._noise_seed, self._noise_draws + i, lo * row)
+            self._noise_draws += count
+            return list(buf)
         shape = (total,) + tuple(x.shape[1:])
-        return [torch.rand(shape, device=x.device, dtype=x.dtype)[lo:hi].contiguous() for _ in range(count)]
+        zs = [torch.rand(shape, device=x.device, dtype=x.dtype)[lo:hi].contiguous() for _ in range(count)]
+        if out is not None:
+            for i in range(count):
+                out[i].copy_(zs[i])
+            return list(out)
+        return zs
 
     def lengths_of(self, x: torch.Tensor) -> List[int]:
         """What Energy.extract_time returns for a batch (data/Energy.py:12-19): every length = T."""
@@ -204,7 +250,7 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, self.lengths_of(x), group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._pass("emb", "rec"):     # one launch sums the partial gradients of the whole pass
             e_loss0.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_side", "rec")
@@ -213,7 +259,7 @@ class TimeGANTrainer:
     def _supervisor_core(self, x):
         n = self.nets
         self._zero("emb", "sup")
-        with self._frozen("emb"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("emb"), self._pass("sup"):     # one launch sums the partial gradients of the whole pass
             s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, self.lengths_of(x), group=self.group)
             s_loss.backward(self._one)
         self._sync_grads("sup")
@@ -233,7 +279,7 @@ class TimeGANTrainer:
     def _joint_g_core(self, x, z, h=None):
         n = self.nets
         self._zero("emb", "rec", "sup", "g", "d")
-        with self._frozen("emb", "rec", "d"), deferred_reductions():   # one launch sums the partial gradients of the pass
+        with self._frozen("emb", "rec", "d"), self._pass("g", "sup"):   # one launch sums the partial gradients of the pass
             g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, self.lengths_of(x), z,
                                               group=self.group, h=None if h is None else h.detach())
             g_loss.backward(self._one)
@@ -244,7 +290,7 @@ class TimeGANTrainer:
     def _joint_e_core(self, x, h=None):
         n = self.nets
         self._zero("emb", "rec", "sup")
-        with self._frozen("sup"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("sup"), self._pass("emb", "rec"):     # one launch sums the partial gradients of the whole pass
             e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, self.lengths_of(x),
                                                          group=self.group, h=h)
             e_loss.backward(self._one)
@@ -263,7 +309,7 @@ class TimeGANTrainer:
         self._zero("emb", "sup", "g", "d")
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, self.lengths_of(x), z,
                                               group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._pass("d"):     # one launch sums the partial gradients of the whole pass
             d_loss.backward(self._one)
         self._sync_grads("d")
         skip = (d_loss.detach() <= self._thr).to(torch.float32)
@@ -291,7 +337,7 @@ class TimeGANTrainer:
         n = self.nets
         self._zero("emb", "rec", "sup")
         e_loss0, _ = losses.embedding_forward_side(n["emb"], n["rec"], x, t, group=self.group)
-        with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._pass("emb", "rec"):     # one launch sums the partial gradients of the whole pass
             e_loss0.backward(self._one)
         self._sync_grads("emb", "rec")
         self._step("emb_side", "rec")
@@ -304,7 +350,7 @@ class TimeGANTrainer:
             return float(loss)
         n = self.nets
         self._zero("emb", "sup")
-        with self._frozen("emb"), deferred_reductions():     # one launch sums the partial gradients of the whole pass
+        with self._frozen("emb"), self._pass("sup"):     # one launch sums the partial gradients of the whole pass
             s_loss, _, _ = losses.supervisor_forward(n["emb"], n["sup"], x, t, group=self.group)
             s_loss.backward(self._one)
         self._sync_grads("sup")
@@ -328,13 +374,11 @@ class TimeGANTrainer:
             zb = self._bufs.get("z11")
             if zb is None or zb.shape[1:] != x.shape:
                 zb = self._bufs["z11"] = torch.empty((11,) + tuple(x.shape), device=x.device, dtype=x.dtype)
-            if noise is None and multi_rank(self.group):
-                noise = self._noise_like(x, 11)
             if noise is not None:
                 for i in range(11):
                     zb[i].copy_(noise[i])
             else:
-                zb.uniform_()
+                self._noise_like(x, 11, out=zb)
             if float(self._thr_host) != self.d_threshold:     # the threshold was changed since the last call
                 self._thr.fill_(self.d_threshold)
                 self._thr_host = self.d_threshold
@@ -362,7 +406,7 @@ class TimeGANTrainer:
                                               group=self.group)
         stepped = bool(d_loss > self.d_threshold)
         if stepped:
-            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            with self._pass("d"):     # one launch sums the partial gradients of the whole pass
                 d_loss.backward(self._one)
             self._sync_grads("d")
             self._step("d")
@@ -377,7 +421,7 @@ class TimeGANTrainer:
         for _ in range(10):
             z = noise.pop(0)
             self._zero("emb", "rec", "sup", "g", "d")
-            with self._frozen("emb", "rec", "d"), deferred_reductions():   # one launch sums the pass's partial gradients
+            with self._frozen("emb", "rec", "d"), self._pass("g", "sup"):   # one launch sums the pass's partial gradients
                 g_loss = losses.generator_forward(n["emb"], n["sup"], n["g"], n["d"], n["rec"], x, t, z,
                                                   group=self.group)
                 g_loss.backward(self._one)
@@ -385,7 +429,7 @@ class TimeGANTrainer:
             self._sync_grads("g", "sup")
             self._step("g", "sup")
             self._zero("emb", "rec", "sup")
-            with self._frozen("sup"), deferred_reductions():     # one launch sums the pass's partial gradients
+            with self._frozen("sup"), self._pass("emb", "rec"):     # one launch sums the pass's partial gradients
                 e_loss, _, _ = losses.embedding_forward_main(n["emb"], n["sup"], n["rec"], x, t, group=self.group)
                 e_loss.backward(self._one)
             out["e_loss"].append(float(e_loss.detach()))
@@ -396,7 +440,7 @@ class TimeGANTrainer:
         d_loss = losses.discriminator_forward(n["emb"], n["sup"], n["g"], n["d"], x, t, z, group=self.group)
         stepped = bool(d_loss > self.d_threshold)
         if stepped:
-            with deferred_reductions():     # one launch sums the partial gradients of the whole pass
+            with self._pass("d"):     # one launch sums the partial gradients of the whole pass
                 d_loss.backward(self._one)
             self._sync_grads("d")
             self._step("d")
@@ -451,13 +495,25 @@ class TimeGANTrainer:
                 if fresh_optimizers:
                     self.reset_optimizers()
                 for epoch in range(epochs[phase]):
-                    for i, x in enumerate(dataset.batches(bs, shuffle=True, generator=gen, rank=r, world=w)):
+                    try:        # where the shard sits in its global batch: the dataset knows by arithmetic
+                        it = dataset.batches(bs, shuffle=True, generator=gen, rank=r, world=w, with_extent=True)
+                        extents = True
+                    except TypeError:
+                        it = dataset.batches(bs, shuffle=True, generator=gen, rank=r, world=w)
+                        extents = False
+                    for i, item in enumerate(it):
+                        x, self._extent = item if extents else (item, None)
+                        if not extents and w > 1:
+                            from .parallel import shard_extent
+                            self._extent = shard_extent(int(x.shape[0]), x.device, self.group)
                         out = steps[phase](x)
                         log.append(out)
                         if on_batch is not None:
                             on_batch(phase, epoch, i, out)
         except StopIteration:
             pass
+        finally:
+            self._extent = None
         return history
 
     def save_models(self, directory: str, dataset: Optional[str] = None, nets: Optional[Sequence[str]] = None) -> List[str]:
