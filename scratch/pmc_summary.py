@@ -1,10 +1,10 @@
 """Summarise the three PMC passes of one workload: python scratch/pmc_summary.py <dir> <c3|c4>
-Reads <dir>/pmc_<wl>_{mfma,fetch,write}_raw.csv, writes <dir>/r02_pmc_traffic_<wl>.json."""
+Reads <dir>/pmc_<wl>_{mfma,fetch,write}_raw.csv, writes <dir>/r03_pmc_traffic_<wl>.json."""
 import collections, csv, json, sys
 out, wl = sys.argv[1], sys.argv[2]
 PASSES = 3        # --steps 1 --warmup 0: the pass that counts launches, one timed pass, the pass that times the halves apart
 # kernels whose streaming reads are 16 bytes per lane: gfx950 tallies those at half their bytes
-WIDE = ("gemm_kernel", "gemm_dma_kernel", "rows_gemm_kernel", "gru_mid_wgrad_kernel", "gru_mid_bwd_kernel", "gru_mid96_fwd_kernel", "gru_mid96_bwd_kernel", "gru_mid_fwd_kernel")
+WIDE = ("gemm_kernel", "gemm_dma_kernel", "rows_gemm_kernel", "gru_mid_wgrad_kernel", "gru_mid_bwd_kernel", "gru_mid96_fwd_kernel", "gru_mid96_bwd_kernel", "gru_mid_fwd_kernel", "gru_persist_fwd_fused_kernel", "gru_persist_fwd_dma_kernel")
 DESC = {"c3": "c3 (B1024 T24 H96 L3)", "c4": "c4 (B2048 T256 H512 L3)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
@@ -37,7 +37,7 @@ res = {"workload": DESC[wl],
                         "bytes), taken as reported for the others (4-byte-per-lane reads: uncalibrated)",
        "kernels": kern, "hbm_bytes_per_step": tot_f + tot_w,
        "fetch_bytes_per_step_corrected": tot_f, "write_bytes_per_step": tot_w}
-json.dump(res, open(f"{out}/r02_pmc_traffic_{wl}.json", "w"), indent=1)
+json.dump(res, open(f"{out}/r03_pmc_traffic_{wl}.json", "w"), indent=1)
 for k, e in sorted(kern.items(), key=lambda kv: -kv[1].get("write_bytes_per_pass", 0)):
     print(k, e)
 print(wl, "HBM bytes per step", tot_f + tot_w)

@@ -169,3 +169,26 @@ def test_fit_with_graphs_equals_eager_fit_including_a_ragged_last_batch():
     np.testing.assert_allclose(h1["supervisor"], h0["supervisor"], rtol=2e-4)
     for h in (h0, h1):      # the joint phase draws its noise differently in the two modes: sanity only
         assert all(np.isfinite(o["d_loss"]) and np.all(np.isfinite(o["g_loss"])) for o in h["joint"])
+
+
+def test_water_windows_keep_raw_values_and_drop_three_columns(tmp_path):
+    """data/Water.py:23-34: drop columns 0, 1 and the last, no reversal, no scaling, windows [i, i + seq_len) for
+    i < len - seq_len.  (The dataset's CSV is not part of the reference checkout; a synthetic table of the same
+    layout -- index, time stamp, six sensor columns, event flag -- stands in.)"""
+    import numpy as np
+    from timegan_amd import data
+    rng = np.random.default_rng(0)
+    sensors = rng.normal(5.0, 3.0, (40, 6))
+    path = tmp_path / "water.csv"
+    with open(path, "w") as f:
+        f.write("idx,Time,Tp,Cl,pH,Redox,Leit,Trueb,EVENT\n")
+        for i, row in enumerate(sensors):
+            f.write(f"{i},2017-07-01T00:{i:02d}:00Z," + ",".join(repr(float(v)) for v in row) + ",False\n")
+    w = data.load_water_csv(str(path), 24)
+    assert w.shape == (16, 24, 6)
+    for i in range(16):      # (pandas' default float parser, which the reference uses too, may be an ulp off)
+        assert np.allclose(w[i].astype(np.float64), sensors[i:i + 24], rtol=1e-14, atol=0)
+    table = np.concatenate([np.arange(40)[:, None], np.zeros((40, 1)), sensors, np.ones((40, 1))], axis=1)
+    ww = data.water_windows(table, 24)
+    assert ww.shape == w.shape and all(np.array_equal(ww[i], sensors[i:i + 24]) for i in range(16))
+    assert data.water_windows(table[:10], 24).shape == (0, 24, 6)

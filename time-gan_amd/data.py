@@ -32,6 +32,34 @@ def load_csv_windows(path: str, seq_len: int) -> np.ndarray:
     return sliding_windows(np.loadtxt(path, delimiter=",", skiprows=1), seq_len)
 
 
+def water_windows(table: np.ndarray, seq_len: int) -> np.ndarray:
+    """The window construction of the water-quality dataset (data/Water.py:23-34) on the table as read from its
+    CSV: the first two columns and the last one are dropped, the rows keep their order and their RAW values (no
+    reversal and no MinMax scaling, unlike Energy / Stock), then every window [i, i + seq_len) for
+    i < len - seq_len.  Returns (N, seq_len, columns - 3)."""
+    data = np.asarray(table)[:, 2:-1]
+    n = len(data) - seq_len
+    if n <= 0:
+        return np.empty((0, seq_len, data.shape[1]), dtype=data.dtype)
+    idx = np.arange(n)[:, None] + np.arange(seq_len)[None, :]
+    return data[idx]
+
+
+def load_water_csv(path: str, seq_len: int) -> np.ndarray:
+    """Water(seq_len, path) (data/Water.py:23-34): a CSV with one header row whose first two columns (an index and
+    a time stamp) and last column (the event label) are not features; read with pandas as the reference does, so
+    that a non-numeric time stamp column is no obstacle."""
+    import pandas as pd
+    frame = pd.read_csv(path)
+    frame = frame.drop([frame.columns[0], frame.columns[1], frame.columns[-1]], axis=1)
+    table = frame.to_numpy()
+    n = len(table) - seq_len
+    if n <= 0:
+        return np.empty((0, seq_len, table.shape[1]), dtype=table.dtype)
+    idx = np.arange(n)[:, None] + np.arange(seq_len)[None, :]
+    return table[idx]
+
+
 def sine_wave(samples_number: int, seq_len: int, features_dim: int,
               rng: Optional[np.random.RandomState] = None) -> np.ndarray:
     """SineWave(samples_number, seq_len, features_dim).get_distribution() as one (N, T, F) array
