@@ -524,8 +524,7 @@ def measure_workload(tg, name, steps, warmup, dev, dist, rank, world, do_ar, use
         achieved = flops / (dev_ms_avg * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None}
-    for tr_file in (os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{name}.json"),
-                    os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{name}.json")):
+    for tr_file in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_{name}.json") for r in (3, 2, 1)):
         if os.path.exists(tr_file):     # HBM bytes per step from separate rocprofv3 --pmc passes of this command
             with open(tr_file) as f:
                 roof["traffic"] = json.load(f)["hbm_bytes_per_step"]

@@ -293,58 +293,6 @@ def test_large_hidden_forward_with_the_projection_inside(B, T, In, H, L, ragged,
     assert tg.persist_timeouts() == 0
 
 
-@pytest.mark.parametrize("B,T,In,H,L,ragged,with_h0,batch_major", [(130, 1, 256, 256, 2, False, False, False),
-                                                                    (200, 4, 192, 192, 3, True, True, False),
-                                                                    (70, 5, 512, 512, 2, True, False, True),
-                                                                    (257, 3, 64, 320, 2, False, True, True)])
-def test_large_hidden_backward_with_the_input_gradient_inside(B, T, In, H, L, ragged, with_h0, batch_major, monkeypatch):
-    """TGRU_STEP_BWD_DX=1: the persistent 64 x 64 backward kernel that forms dX itself (the r and z tiles of dg
-    multiplied with W_hh and W_ih at once, the n part of dX under the hand-off; measured slower than the default,
-    kept as a variant) against the recurrence followed by the batched dX product: through the C ABI, time-major
-    and batch-major, with and without an initial state (dh0), uniform and ragged lengths, a single step, a bottom
-    layer whose input is narrower than the state (not fused there)."""
-    import timegan_amd as tg
-    for k in ("TGRU_NO_STEP", "TGRU_NO_PERSIST", "TGRU_NO_STEP_DMA", "TGRU_NO_STEP_FUSE", "TGRU_STEP_BWD_WIDE"):
-        monkeypatch.delenv(k, raising=False)
-    g = torch.Generator().manual_seed(B + T)
-    k = 1.0 / H ** 0.5
-    ws = []
-    for l in range(L):
-        in_l = In if l == 0 else H
-        for shape in ((3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)):
-            ws.append(((torch.rand(shape, generator=g) * 2 - 1) * k).cuda())
-    shape = (B, T) if batch_major else (T, B)
-    x = torch.rand(*shape, In, generator=g).cuda()
-    dy = torch.randn(*shape, H, generator=g).cuda()
-    h0 = torch.randn(L, B, H, generator=g).cuda() if with_h0 else None
-    dh_n = torch.randn(L, B, H, generator=g).cuda()
-    lens = None
-    if ragged:
-        lens = torch.tensor(sorted((1 + (7 * i) % T for i in range(B)), reverse=True), dtype=torch.int32).cuda()
-    layout = tg.LAYOUT_BTF if batch_major else tg.LAYOUT_TBF
-    outs = []
-    for fuse in (True, False):
-        if fuse:
-            monkeypatch.setenv("TGRU_STEP_BWD_DX", "1")
-        else:
-            monkeypatch.delenv("TGRU_STEP_BWD_DX")
-        tg.reload_switches()
-        n0 = tg.launch_count()
-        outs.append(tg.gru_forward_backward_raw(x, ws, B, T, layout, dy, h0=h0, dh_n=dh_n, lengths=lens))
-        outs[-1]["launches"] = tg.launch_count() - n0
-        torch.cuda.synchronize()
-    a, b = outs
-    fused_bwd = (L if In == H else L - 1) if H % 64 == 0 else 0
-    assert a["launches"] == b["launches"] - fused_bwd     # a dX product less per fused layer
-    assert_close(a["y"].cpu().numpy(), b["y"].cpu().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y")
-    assert_close(a["dx"].cpu().numpy(), b["dx"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
-    if with_h0:
-        assert_close(a["dh0"].cpu().numpy(), b["dh0"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dh0")
-    for i, (p, q) in enumerate(zip(a["grads"], b["grads"])):
-        assert_close(p.cpu().numpy(), q.cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"grad {i}")
-    assert tg.persist_timeouts() == 0
-
-
 def test_large_hidden_row_tiles_are_resident_per_xcd(monkeypatch):
     """A persistent launch must fit PER XCD (workgroup ids go round the eight XCDs, each XCD has an eighth of
     the compute units): 21 row tiles of twelve workgroups (B 2688, H 384) are three row tiles per XCD = 36

@@ -1145,281 +1145,6 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_sq_kernel(PersistBwd s) {
 
 
 // ----------------------------------------------------------------------------------------------
-// The 64 x 64 backward kernel WITH THE INPUT GRADIENT INSIDE (layer input as wide as the state, H a multiple of 64).
-// dX_{t+1} = dgi_{t+1} . W_ih and the recurrent product dgh_{t+1} . W_hh of step t read the SAME rows of dg: their
-// r and z columns are identical (two thirds of the reduction), only the n gate differs (da_n for the input, da_n * r
-// for the state).  A backward step is bound by the bytes its workgroup takes from the L2, so:
-//   * over the r and z columns ONE k-tile of dg is multiplied with the k-tiles of both W_hh and W_ih (three tiles
-//     fetched for two products instead of four);
-//   * the n part of the recurrent product follows, then the gates of step t, its dg tile, the arrival;
-//   * the n part of dX_{t+1} needs nothing from the peers' step t: it runs AFTER the arrival, under the hand-off.
-// The batched dX product of the layer (a pass of its own over all of dg) is gone.  One more round of the loop
-// (t = -1) forms dX_0, and the gradient of the initial state when that is wanted.
-// MEASURED SLOWER than the recurrence followed by the batched product, and therefore only selected by
-// TGRU_STEP_BWD_DX=1: at B 2048, T 256, H 512 a layer takes 19.0 ms here against 9.97 + 5.9 ms.  The products of a
-// register-staged persistent kernel run at about 0.7 of the matrix pipe's rate (operand tiles cross from registers
-// to LDS between the products of a workgroup that is alone on its CU, one barrier per k-tile) where the batched
-// loader-wave GEMM runs at 0.9: moving the dX product in here costs more than the shared tiles (1.28 MB instead of
-// 1.57 MB per step) and the covered hand-off give back.  k-tile 64 needs 526 registers (spills); k-tile 32 with two
-// or four tiles in flight: 93.8 / 92.6 ms per C4 backward pass against 83.8.
-// ----------------------------------------------------------------------------------------------
-#ifndef TGRU_SQX_BK
-#define TGRU_SQX_BK 32
-#endif
-#ifndef TGRU_SQX_DEPTH
-#define TGRU_SQX_DEPTH 4
-#endif
-template <int BK>
-__global__ __launch_bounds__(256) void gru_persist_bwd_sqx_kernel(PersistBwd s) {
-    constexpr int kRows = 64, kUnits = 64;       // (shadow the 128 x 32 geometry of the other kernels)
-    constexpr int LDK = BK + 4, LDB = kUnits + 4, LDH = kUnits + 4;
-    static_assert(BK % 16 == 0, "k-tile");
-    // LDS: two dg tiles, two W_hh tiles, two W_ih tiles; the gate-gradient tiles on their way out lie over the first four
-    constexpr int kTileFloats = 2 * kRows * LDK + 4 * BK * LDB, kOutFloats = 4 * kRows * LDH;
-    __shared__ __attribute__((aligned(16))) float lds[kTileFloats > kOutFloats ? kTileFloats : kOutFloats];
-    float (*As)[kRows][LDK] = reinterpret_cast<float (*)[kRows][LDK]>(lds);
-    float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * kRows * LDK);
-    float (*Xs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * kRows * LDK + 2 * BK * LDB);
-    float (*Gs)[kRows][LDH] = reinterpret_cast<float (*)[kRows][LDH]>(lds);
-    __shared__ int Ls[kRows];
-    int mt, nt;
-    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
-    mt += s.mt0;
-    const BwdArgs &a = s.b;
-    const int H = a.H, B = a.B, T = a.T, NT = H / kUnits;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = lane & 31, lk = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = mt * kRows, u0 = nt * kUnits;
-    const int u = u0 + 32 * wc + lrow;
-    unsigned *cnt = s.sync + 1 + mt;
-    const long plane = (long)T * B * H;
-    const long step_bytes = (long)B * 4 * H * 4;      // one step's rows of dg
-
-    if (tid < kRows) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
-    __syncthreads();
-    int roff[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) roff[r] = (min(m0 + 32 * wr + d_row(r, lk), B - 1) * H + u) * 4;
-    const long bh_bytes = (long)B * H * 4;
-    const int dy_bt = a.dymap.mode == 1, dx_bt = a.dxmap.mode == 1;
-    float cin[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mc = min(m0 + 32 * wr + d_row(r, lk), B - 1);
-        cin[r] = a.dh_n ? a.dh_n[(long)mc * H + u] : 0.f;
-    }
-    const bool dy_ext = a.dy_ext != nullptr;
-    float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f;
-
-    constexpr int KQ = BK / 4, PA = kRows * KQ / 256, PB = BK * 16 / 256;
-    static_assert(BK * 16 % 256 == 0 && kRows * KQ % 256 == 0, "whole slots per thread");
-    int a_off[PA];
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
-        a_off[p] = (min(m0 + row, B - 1) * 4 * H + kc) * 4;
-    }
-    const int b_k = tid >> 4, b_c = (tid & 15) << 2;     // slot p of this thread: k = b_k + 16 p
-    const float *b_src = a.w_hh + (long)b_k * H + u0 + b_c;
-    const float *x_src = a.w_ih + (long)b_k * H + u0 + b_c;      // (the layer input is H wide: same row length)
-    struct Regs { float4 a[PA], b[PB], x[PB]; };
-    const int nRZ = 2 * H / BK, nN = H / BK;
-    constexpr int kDepth = TGRU_SQX_DEPTH;     // tiles in flight ahead of the products (even)
-
-    for (int t = T - 1; t >= -1; --t) {
-        const int tc = max(t, 0);
-        f32x16 acc_h[2], acc_x[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc_h[g][r] = 0.f; acc_x[g][r] = 0.f; }
-        const bool have_next = t < T - 1;          // dg of step t+1 exists: a recurrent product and a dX to form
-        const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg + (long)min(t + 1, T - 1) * B * 4 * H, step_bytes);
-
-        // One pass over n tiles of the ring.  PHASE 1: tiles [0, nRZ) carry the r and z columns for BOTH products,
-        // tiles [nRZ, nRZ + nN) the n columns (da_n * r) of the recurrent product.  PHASE 2: the n columns (da_n) of dX.
-        auto a_col = [&](int phase, int i) { return phase == 2 ? 2 * H + i * BK : (i < nRZ ? i * BK : 3 * H + (i - nRZ) * BK); };
-        auto b_row = [&](int phase, int i) { return phase == 2 ? 2 * H + i * BK : (i < nRZ ? i * BK : 2 * H + (i - nRZ) * BK); };
-        auto load_a = [&](int phase, int i, Regs &g) {
-            const int kcol = a_col(phase, i);
-#pragma unroll
-            for (int p = 0; p < PA; ++p) g.a[p] = ld4_sc1(rs_dg, a_off[p] + kcol * 4);
-        };
-        auto load_b = [&](int phase, int i, Regs &g) {      // W_hh rows for the state (phase 1), W_ih rows for the input
-            const int k0 = b_row(phase, i);
-            if (phase == 1) {
-#pragma unroll
-                for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(b_src + (long)(k0 + 16 * p) * H);
-                if (i < nRZ) {
-#pragma unroll
-                    for (int p = 0; p < PB; ++p) g.x[p] = *reinterpret_cast<const float4 *>(x_src + (long)(k0 + 16 * p) * H);
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < PB; ++p) g.b[p] = *reinterpret_cast<const float4 *>(x_src + (long)(k0 + 16 * p) * H);
-            }
-        };
-        auto store_tiles = [&](int phase, int i, int buf, const Regs &g) {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                const int slot = tid + p * 256, row = slot / KQ, kc = (slot % KQ) << 2;
-                *reinterpret_cast<float4 *>(&As[buf][row][kc]) = g.a[p];
-            }
-#pragma unroll
-            for (int p = 0; p < PB; ++p) *reinterpret_cast<float4 *>(&Bs[buf][b_k + 16 * p][b_c]) = g.b[p];
-            if (phase == 1 && i < nRZ) {
-#pragma unroll
-                for (int p = 0; p < PB; ++p) *reinterpret_cast<float4 *>(&Xs[buf][b_k + 16 * p][b_c]) = g.x[p];
-            }
-        };
-        auto products = [&](int phase, int i, int cur, int q0, int q1) {
-            const bool both = phase == 1 && i < nRZ;
-            for (int q = q0; q < q1; ++q) {      // chunk q: eight k-steps, four per lane half
-                const int k = 8 * q + 4 * lk;
-                const float4 av = *reinterpret_cast<const float4 *>(&As[cur][32 * wr + lrow][k]);
-                const float b0 = Bs[cur][k][32 * wc + lrow], b1 = Bs[cur][k + 1][32 * wc + lrow];
-                const float b2 = Bs[cur][k + 2][32 * wc + lrow], b3 = Bs[cur][k + 3][32 * wc + lrow];
-                if (phase == 1) {
-                    acc_h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc_h[0], 0, 0, 0);
-                    acc_h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc_h[1], 0, 0, 0);
-                    acc_h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc_h[0], 0, 0, 0);
-                    acc_h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc_h[1], 0, 0, 0);
-                    if (both) {
-                        const float x0 = Xs[cur][k][32 * wc + lrow], x1 = Xs[cur][k + 1][32 * wc + lrow];
-                        const float x2 = Xs[cur][k + 2][32 * wc + lrow], x3 = Xs[cur][k + 3][32 * wc + lrow];
-                        acc_x[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x0, acc_x[0], 0, 0, 0);
-                        acc_x[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x1, acc_x[1], 0, 0, 0);
-                        acc_x[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x2, acc_x[0], 0, 0, 0);
-                        acc_x[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x3, acc_x[1], 0, 0, 0);
-                    }
-                } else {
-                    acc_x[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc_x[0], 0, 0, 0);
-                    acc_x[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc_x[1], 0, 0, 0);
-                    acc_x[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc_x[0], 0, 0, 0);
-                    acc_x[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc_x[1], 0, 0, 0);
-                }
-            }
-        };
-        // the ring of one phase: tiles kDepth ahead of the products in registers, two LDS buffers
-        auto run = [&](int phase, int n, bool wait) {
-            Regs ring[kDepth];
-            // the weight halves of the first tiles depend on nobody: requested before the wait for the peers
-#pragma unroll
-            for (int d = 0; d < kDepth; ++d) load_b(phase, min(d, n - 1), ring[d]);
-            if (wait) wait_for_peers(cnt, (unsigned)(NT * (T - 1 - t)), s.err, s.spin_limit);
-#pragma unroll
-            for (int d = 0; d < kDepth; ++d) load_a(phase, min(d, n - 1), ring[d]);
-            store_tiles(phase, 0, 0, ring[0]);
-            load_a(phase, min(kDepth, n - 1), ring[0]);
-            load_b(phase, min(kDepth, n - 1), ring[0]);
-            __syncthreads();
-            for (int kt0 = 0; kt0 < n; kt0 += kDepth) {
-#pragma unroll
-                for (int d = 0; d < kDepth; ++d) {
-                    const int kt = kt0 + d, cur = kt & 1;
-                    if (kt < n) {
-                        products(phase, kt, cur, 0, BK / 16);
-                        if (kt + 1 < n) {
-                            store_tiles(phase, kt + 1, cur ^ 1, ring[(d + 1) % kDepth]);
-                            const int nx = min(kt + 1 + kDepth, n - 1);
-                            load_a(phase, nx, ring[(d + 1) % kDepth]);
-                            load_b(phase, nx, ring[(d + 1) % kDepth]);
-                        }
-                        products(phase, kt, cur, BK / 16, BK / 8);
-                        __syncthreads();
-                    }
-                }
-            }
-        };
-        if (have_next) run(1, (t >= 0 || a.dh0) ? nRZ + nN : nRZ, true);
-        // operands of the gate gradients of step t.  (Requested only now: held across the products, as the kernel
-        // without dX holds them, they cost ninety-six registers that the second set of accumulators and the W_ih
-        // tiles in the ring need; the matrix pipe pays their latency once per step.)
-        float gr[16], gz[16], gn[16], ghn[16], hp[16], dy[16];
-        if (t >= 0) {
-            const float *gt = a.gates + (long)tc * B * H;
-            const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
-                                         rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
-            const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
-            const bool bt = dy_ext && dy_bt;
-            const __amdgpu_buffer_rsrc_t rs_d =
-                dy_ext ? rsrc_of(a.dy_ext + (bt ? (long)tc * H : (long)tc * B * H), bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes)
-                       : rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                gr[r] = ld1(rs_r, roff[r], 0); gz[r] = ld1(rs_z, roff[r], 0);
-                gn[r] = ld1(rs_n, roff[r], 0); ghn[r] = ld1(rs_h, roff[r], 0);
-                hp[r] = ld1(rs_hp, roff[r], 0);
-                dy[r] = ld1(rs_d, bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r], 0);
-            }
-        }
-
-        if (t < 0) {   // gradient of the initial state
-            if (a.dh0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + 32 * wr + d_row(r, lk);
-                    if (m < B) a.dh0[(long)m * H + u] = cin[r] + acc_h[0][r] + acc_h[1][r];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wr + d_row(r, lk);
-                const bool active = t < Ls[row];
-                const float dhc = cin[r] + acc_h[0][r] + acc_h[1][r];
-                const float d = active ? dy[r] + dhc : 0.f;
-                const float dn = d * (1.f - gz[r]);
-                const float dzz = d * (hp[r] - gn[r]);
-                const float an = active ? dn * (1.f - gn[r] * gn[r]) : 0.f;
-                const float dar = active ? an * ghn[r] * gr[r] * (1.f - gr[r]) : 0.f;
-                const float daz = active ? dzz * gz[r] * (1.f - gz[r]) : 0.f;
-                const float dgn = active ? an * gr[r] : 0.f;
-                cin[r] = active ? d * gz[r] : dhc;
-                Gs[0][row][32 * wc + lrow] = dar; Gs[1][row][32 * wc + lrow] = daz; Gs[2][row][32 * wc + lrow] = an; Gs[3][row][32 * wc + lrow] = dgn;
-                sr += dar; sz += daz; sn += an; sg += dgn;
-            }
-            __syncthreads();
-            {
-                const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(a.dg + (long)t * B * 4 * H, step_bytes);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int p = 0; p < kRows * (kUnits / 4) / 256; ++p) {
-                        const int slot = tid + p * 256, row = slot >> 4, c4 = (slot & 15) << 2;
-                        const float4 v = *reinterpret_cast<const float4 *>(&Gs[q][row][c4]);
-                        const int off = m0 + row < B ? ((m0 + row) * 4 * H + q * H + u0 + c4) * 4 : 0x7fffffff;
-                        st4_sc1(rs_o, off, v);
-                    }
-            }
-            arrive(cnt);     // (also keeps Gs from being rewritten before every wave has read it)
-        }
-        if (have_next) {
-            // the n columns of dX_{t+1}, under the hand-off of step t; then this tile of dX_{t+1} leaves (nobody in this
-            // launch reads it: plain stores).  Rows of the caller's dx are time-major or batch-major.
-            run(2, nN, false);
-            const int tx = t + 1;
-            const __amdgpu_buffer_rsrc_t rs_x =
-                rsrc_of(a.dx + (dx_bt ? (long)tx * H : (long)tx * B * H), dx_bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * wr + d_row(r, lk);
-                const int off = m < B ? (dx_bt ? (roff[r] - 4 * u) * T + 4 * u : roff[r]) : 0x7fffffff;
-                st1(rs_x, off, 0, acc_x[0][r] + acc_x[1][r]);
-            }
-        }
-    }
-
-    sr += __shfl_xor(sr, 32); sz += __shfl_xor(sz, 32); sn += __shfl_xor(sn, 32); sg += __shfl_xor(sg, 32);
-    if (lk == 0) {
-        float *p = a.db_part + (long)(mt * 2 + wr) * 4 * H + u;
-        p[0] = sr; p[H] = sz; p[2 * H] = sn; p[3 * H] = sg;
-    }
-}
-
-
-// ----------------------------------------------------------------------------------------------
 // Loader-wave variant of the persistent forward kernel.  Moving an operand tile from registers into LDS
 // (ds_write_b128) is not covered by the products: the matrix pipe waits while the data crosses from the
 // register file, and with one workgroup per CU no other wave fills the gap (one MFMA per 80 cycles where the
@@ -2013,17 +1738,6 @@ bool gru_step_fwd_fuses(const FwdArgs &a) {
     return x_bytes < (1L << 31) && (long)3 * a.H * a.In * 4 < (1L << 31);
 }
 
-// The 64 x 64 backward kernel with dX inside: the layer input as wide as the state, H a multiple of 64, the caller's
-// dx time-major or batch-major and below 2 GiB (32-bit byte offsets), dy from one tensor only.
-bool gru_step_bwd_fuses_dx(const BwdArgs &a) {
-    if (!switches().step_bwd_dx || switches().step_bwd_wide || !a.dx || !a.w_ih || a.In != a.H || a.H % 64 != 0) return false;
-    if (!gru_step_persistent(a.B, a.H) || (a.dy_int && a.dy_ext)) return false;
-    if (a.dxmap.mode != 0 && a.dxmap.mode != 1) return false;
-    if ((reinterpret_cast<uintptr_t>(a.w_ih) | reinterpret_cast<uintptr_t>(a.dx)) & 15) return false;
-    const bool dy_ok = !a.dy_ext || a.dymap.mode == 0 || (a.dymap.mode == 1 && (long)a.B * a.T * a.H * 4 < (1L << 31));
-    return dy_ok && (long)a.B * a.T * a.H * 4 < (1L << 31) && (size_t)a.B * a.H >= gru_step_sync_words(a.B);
-}
-
 bool gru_step_persistent(int B, int H) {
     return gru_step_supported(B, H) && !switches().no_persist && persist_row_tiles(H / kUnits) > 0 &&
            (long)B * 4 * H * 4 < (1L << 31);
@@ -2160,12 +1874,12 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hi
                 k.b = a;
                 k.sync = sync;
                 k.err = err;
+            k.err = err;
                 k.mt0 = mt0;
                 k.MT = min(per2, MT2 - mt0);
                 k.mtx = (k.MT + 7) / 8;
                 k.spin_limit = switches().spin_limit;
-                if (gru_step_bwd_fuses_dx(a)) TGRU_LAUNCH(gru_persist_bwd_sqx_kernel<TGRU_SQX_BK>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
-                else TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
             }
             return hipGetLastError();
         }

@@ -22,7 +22,6 @@ void Switches::read() {
     no_step_dma = on("TGRU_NO_STEP_DMA");
     no_step_fuse = on("TGRU_NO_STEP_FUSE");
     step_bwd_wide = on("TGRU_STEP_BWD_WIDE");
-    step_bwd_dx = on("TGRU_STEP_BWD_DX");
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
     no_fuse = on("TGRU_NO_FUSE");
@@ -90,7 +89,6 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
 //   TGRU_NO_STEP_FUSE=1   H > 128: the layer's input projection as a batched GEMM instead of inside the forward kernel
-//   TGRU_STEP_BWD_DX=1    H > 128: the 64 x 64 backward kernel also forms dX (measured slower than the batched product)
 //   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
 //   TGRU_SPIN_LIMIT=n     H > 128: polls after which a wait of a persistent kernel gives up (default 2^24)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)
@@ -630,12 +628,10 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         // the gradient of the layer's input: the layer below's dy (or the caller's dx)
         float *dx_l = l == 0 ? dx : workspace + w.dyb + (size_t)(l & 1) * dyb_stride;
         b.w_ih = w_ih[l]; b.In = In_l; b.dx = dx_l; b.dxmap = l == 0 ? ext_map(d, toff) : id_map(d);
-        // kernels that form dX themselves: the H = 96 kernel, and the persistent H > 128 kernel where it can
-        const bool step_dx = stepk && err && gru_step_bwd_fuses_dx(b);
-        const bool fused_dx = (mid && !stepk && gru_mid96_bwd_supported(b)) || step_dx;
-        if (fused_dx && !step_dx && !want_w) b.dg = nullptr;      // neither dX nor a weight-gradient stage will read dg
+        const bool fused_dx = mid && !stepk && gru_mid96_bwd_supported(b);    // that kernel forms dX itself
+        if (fused_dx && !want_w) b.dg = nullptr;      // neither dX nor a weight-gradient stage will read dg
         if (stepk) TGRU_HIP(launch_gru_step_bwd(b, workspace + w.carry, err, s));
-        else if (fused_dx && !step_dx) TGRU_HIP(launch_gru_mid96_bwd(b, s));
+        else if (fused_dx) TGRU_HIP(launch_gru_mid96_bwd(b, s));
         else if (mid) TGRU_HIP(launch_gru_mid_bwd(b, s));
         else TGRU_HIP(launch_gru_bwd(b, s));
         const bool mid_wgrad = mid && gru_mid_wgrad_supported(B, T, In_l, H) &&

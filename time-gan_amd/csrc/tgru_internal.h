@@ -21,7 +21,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, no_step_fuse, step_bwd_wide, step_bwd_dx, no_wide_head;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, no_step_fuse, step_bwd_wide, no_wide_head;
     int spin_limit;     // polls after which a wait of the persistent H > 128 kernels gives up (TGRU_SPIN_LIMIT)
     void read();
     Switches() { read(); }
@@ -252,9 +252,6 @@ bool gru_step_persistent(int B, int H);
 // Will launch_gru_step_fwd compute this layer's input projection itself (a.x, a.xmap, a.In, a.w_ih, a.b_ih set)?
 // Then a.gi is not read and the caller skips the projection GEMM.
 bool gru_step_fwd_fuses(const FwdArgs &a);
-// Will launch_gru_step_bwd form the gradient of the layer's input itself (a.w_ih, a.dx, a.dxmap, a.In set)?  Then the
-// caller skips the dX product over dg.
-bool gru_step_bwd_fuses_dx(const BwdArgs &a);
 // One library call has one error word (a 32-bit word of its workspace): a wait of a persistent kernel that gives
 // up sets it.  gru_step_begin zeroes it before the first layer; gru_step_check, after the last layer, launches
 // one wave that -- if the word is set -- fills the first ns[k] floats of every outs[k] (null entries skipped, at
