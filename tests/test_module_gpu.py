@@ -177,14 +177,17 @@ def test_energy_width_with_initial_state_and_ragged_lengths(switches, batch_firs
 
 
 @pytest.mark.parametrize("family", ["persistent_tiles", "persistent_tiles_unfused", "persistent_tiles_staged",
-                                    "persistent_tiles_wide_backward", "launch_per_step", "sixteen_sequences"])
+                                    "persistent_tiles_streamed_backward", "persistent_tiles_wide_backward",
+                                    "launch_per_step", "sixteen_sequences"])
 def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch):
     """H > 128 in multiples of 32 runs on 128-sequence x 32-unit tiles with the time loop inside the kernel
     (the workgroups of a row tile synchronise through counters; the forward kernel's operand tiles are fetched
     by loader waves and the layer's input projection runs inside it where the input width is a multiple of 32,
     TGRU_NO_STEP_FUSE=1 leaves the projection to the batched GEMM, TGRU_NO_STEP_DMA=1 stages the tiles through
     registers; the backward kernel works on 64 x 64
-    tiles where H is a multiple of 64, TGRU_STEP_BWD_WIDE=1 keeps it on 128 x 32); TGRU_NO_PERSIST=1 gives the
+    tiles where H is a multiple of 64 -- with its tile of W_hh resident in registers and LDS, two chains of 32
+    sequences worked alternately, at H = 256 / 384 / 512, TGRU_NO_STEP_RES=1 streams the W_hh tiles there too --
+    and TGRU_STEP_BWD_WIDE=1 keeps it on 128 x 32); TGRU_NO_PERSIST=1 gives the
     same tiles with one launch per time step, TGRU_NO_STEP=1 the 16-sequence kernels: all on the same cases."""
     import timegan_amd as tg
     monkeypatch.delenv("TGRU_NO_STEP", raising=False)
@@ -192,6 +195,9 @@ def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch)
     monkeypatch.delenv("TGRU_NO_STEP_DMA", raising=False)
     monkeypatch.delenv("TGRU_NO_STEP_FUSE", raising=False)
     monkeypatch.delenv("TGRU_STEP_BWD_WIDE", raising=False)
+    monkeypatch.delenv("TGRU_NO_STEP_RES", raising=False)
+    if family == "persistent_tiles_streamed_backward":
+        monkeypatch.setenv("TGRU_NO_STEP_RES", "1")
     if family == "persistent_tiles_unfused":
         monkeypatch.setenv("TGRU_NO_STEP_FUSE", "1")
     elif family == "persistent_tiles_staged":
@@ -205,6 +211,8 @@ def test_large_hidden_with_initial_state_and_ragged_lengths(family, monkeypatch)
     tg.reload_switches()
     for (B, T, In, H, L, lens) in ((300, 5, 40, 160, 2, [5] * 100 + [4] * 50 + [2] * 100 + [1] * 50),
                                    (130, 3, 256, 256, 1, None),
+                                   (70, 4, 64, 512, 2, [4] * 30 + [3] * 20 + [1] * 20),
+                                   (200, 3, 32, 384, 2, None),
                                    (5, 7, 20, 192, 3, [7, 7, 3, 2, 1])):
         torch.manual_seed(B + H)
         ref = nn.GRU(In, H, L, batch_first=True)
@@ -291,6 +299,50 @@ def test_large_hidden_forward_with_the_projection_inside(B, T, In, H, L, ragged,
     for i, (p, q) in enumerate(zip(a["grads"], b["grads"])):
         assert_close(p.cpu().numpy(), q.cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"grad {i}")
     assert tg.persist_timeouts() == 0
+
+
+@pytest.mark.parametrize("B,T,In,H,L,ragged,with_h0", [(300, 6, 64, 512, 2, True, True),
+                                                        (2048, 3, 512, 512, 1, False, False),    # one workgroup per CU
+                                                        (2500, 4, 32, 256, 2, True, True),      # several launches
+                                                        (129, 5, 96, 384, 3, False, True)])
+def test_large_hidden_backward_with_resident_recurrent_weights(B, T, In, H, L, ragged, with_h0, monkeypatch):
+    """The backward recurrence that keeps its tile of W_hh in registers and LDS (waves split k and fetch their own
+    operand tiles, two chains of 32 sequences per workgroup with a counter each) against the kernel that streams
+    the W_hh tiles, on the same calls: ragged lengths, an initial state (dh0 = one more product), batches that end
+    inside a tile, more row tiles than one launch holds."""
+    import timegan_amd as tg
+    for k in ("TGRU_NO_STEP", "TGRU_NO_PERSIST", "TGRU_NO_STEP_DMA", "TGRU_NO_STEP_FUSE", "TGRU_STEP_BWD_WIDE",
+              "TGRU_NO_STEP_RES"):
+        monkeypatch.delenv(k, raising=False)
+    g = torch.Generator().manual_seed(B + T)
+    k = 1.0 / H ** 0.5
+    ws = []
+    for l in range(L):
+        in_l = In if l == 0 else H
+        for shape in ((3 * H, in_l), (3 * H, H), (3 * H,), (3 * H,)):
+            ws.append(((torch.rand(shape, generator=g) * 2 - 1) * k).cuda())
+    x = torch.rand(T, B, In, generator=g).cuda()
+    dy = torch.randn(T, B, H, generator=g).cuda()
+    dh_n = torch.randn(L, B, H, generator=g).cuda()
+    h0 = torch.randn(L, B, H, generator=g).cuda() if with_h0 else None
+    lens = None
+    if ragged:
+        lens = torch.tensor(sorted((1 + (7 * i) % T for i in range(B)), reverse=True), dtype=torch.int32).cuda()
+    tg.persist_timeouts()
+    outs = []
+    for resident in (True, False):
+        if not resident:
+            monkeypatch.setenv("TGRU_NO_STEP_RES", "1")
+        tg.reload_switches()
+        outs.append(tg.gru_forward_backward_raw(x, ws, B, T, tg.LAYOUT_TBF, dy, h0=h0, dh_n=dh_n, lengths=lens))
+        torch.cuda.synchronize()
+    a, b = outs
+    assert tg.persist_timeouts() == 0
+    assert_close(a["dx"].cpu().numpy(), b["dx"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx")
+    if with_h0:
+        assert_close(a["dh0"].cpu().numpy(), b["dh0"].cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dh0")
+    for i, (p, q) in enumerate(zip(a["grads"], b["grads"])):
+        assert_close(p.cpu().numpy(), q.cpu().numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"grad {i}")
 
 
 def test_large_hidden_row_tiles_are_resident_per_xcd(monkeypatch):

@@ -1686,6 +1686,334 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_fused_kernel(Per
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Backward recurrence with W_hh RESIDENT in the workgroup (H a multiple of 128).
+//
+// A step of the 64 x 64 kernel above is bound by the bytes its CU takes from the L2, 0.8 MB of operand tiles for
+// 12.6 MFLOP, half of them the workgroup's 3H x 64 tile of W_hh -- the same tile at every step.  The tile is
+// 3H x 64 floats (384 KiB at H = 512): more than LDS, less than LDS plus the register file of four waves that have
+// a SIMD each (512 registers per lane).  So each wave keeps a QUARTER OF THE K RANGE of the tile for good -- the
+// MFMA B operands of its 3H/4 values of k, most of them in registers, the rest in LDS -- and multiplies the whole
+// 64-unit width with it:
+//   * the waves of a workgroup split k, not the output: a wave needs columns [w 3H/4, (w+1) 3H/4) of the row tile's
+//     dg rows and nothing else, so its operand tiles are private to it.  It fetches them itself with
+//     direct-to-LDS loads into its own ring of slots and reads them back after a count of its own loads: no
+//     barrier inside the product, no register staging, and only the dg rows (half the bytes) cross from the L2;
+//   * the four partial 32 x 64 sums meet in LDS once per product; each wave sums -- in wave order -- the eight rows
+//     it then owns for the gate arithmetic;
+//   * the 64 sequences of a row tile are two independent chains of 32 (a sequence only ever needs its own row of
+//     dg), each with its own arrival counter, worked alternately: while the workgroups of a row tile drain their
+//     stores of one half, arrive and wait for each other, every one of them multiplies the other half.  With
+//     W_hh resident the second product costs no second pass over the matrix.
+// Needs every workgroup of the launch resident, like the other persistent kernels; every wait is bounded.
+// ----------------------------------------------------------------------------------------------
+namespace res {
+#ifndef TGRU_RES_SLOTS
+#define TGRU_RES_SLOTS 3
+#endif
+constexpr int kSlots = TGRU_RES_SLOTS;      // ring slots per wave: one being read, the others in flight
+constexpr int KS = 32;                      // k per slot: 32 rows x 32 k = 4 KiB = four load instructions of a wave
+__device__ __forceinline__ void wait_loads(int n) {      // (n is a constant once the stage loop is unrolled)
+    switch (n) {
+    case 12: pd::wait_vmcnt<12>(); break;
+    case 8: pd::wait_vmcnt<8>(); break;
+    case 4: pd::wait_vmcnt<4>(); break;
+    default: pd::wait_vmcnt<0>(); break;
+    }
+}
+__device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, sbase, kAuxSc1);
+}
+// A direct-to-LDS load the compiler does not know to be one.  A wave of this kernel both requests its operand
+// tiles and reads them back, and the compiler makes every LDS read that follows a direct-to-LDS load it knows of
+// wait for ALL vector-memory loads in flight (it cannot tell which LDS bytes the load writes): the ring would
+// never hold more than the tile being waited for.  Written as an instruction the compiler does not look into,
+// the load is ordered against the LDS reads by this kernel's own counts (wait_loads) and compiler barriers.
+// The descriptor is the four words make_buffer_rsrc would build (raw buffer, 32-bit elements).
+__device__ __forceinline__ u32x4 desc_words(const void *p, long bytes) {
+    const unsigned long v = reinterpret_cast<unsigned long>(p);
+    u32x4 d;
+    d.x = (unsigned)v; d.y = (unsigned)(v >> 32) & 0xffffu; d.z = (unsigned)bytes; d.w = 0x00020000u;
+    return d;
+}
+__device__ __forceinline__ void dma16_sc1(u32x4 rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+}  // namespace res
+
+template <int H, int NCL>     // NCL: how many of a wave's 3H/32 chunks (eight k) of W_hh live in LDS, not registers
+__global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) {
+    using namespace pd;
+    constexpr int kR = 64, kU = 64;
+    constexpr int KW = 3 * H / 4, NC = KW / 8, NCR = NC - NCL;          // a wave's k range, in chunks of eight
+    constexpr int KS = res::KS, NST = KW / KS, CPS = KS / 8, NS = res::kSlots;
+    static_assert(H % 128 == 0 && KW % KS == 0 && NCL >= 0 && NCL < NC && NS >= 2 && NS <= 4, "shape");
+    constexpr int kRingF = 4 * NS * 1024, kWlF = 4 * NCL * 2 * 256, kXF = 16 * 2 * 256;       // floats
+    static_assert((kRingF + kWlF + kXF) * 4 + kR * 4 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) float lds[kRingF + kWlF + kXF];
+    __shared__ int Ls[kR];         // length of each sequence of the row tile (0 for rows past the batch)
+    int mt, nt;
+    if (!tile_of(s.MT, s.mtx, mt, nt)) return;
+    mt += s.mt0;
+    const BwdArgs &a = s.b;
+    const int B = a.B, T = a.T, NT = H / kU;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int m0 = mt * kR, u0 = nt * kU;
+    unsigned *cnt = s.sync + 1 + 2 * mt;           // [half]
+    const long plane = (long)T * B * H;
+    const long step_bytes = (long)B * 4 * H * 4, bh_bytes = (long)B * H * 4;
+    float *ring = lds + wave * (NS * 1024);
+    const unsigned ring_addr = (unsigned)(unsigned long)(lds_void *)ring;      // (LDS byte address, same in every lane)
+    const float4 *Wl = reinterpret_cast<const float4 *>(lds + kRingF) + wave * (NCL * 2 * 64) + lane;
+    float4 *X = reinterpret_cast<float4 *>(lds + kRingF + kWlF);        // [owner wave][source wave][unit block][lane]
+
+    if (tid < kR) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+
+    // ---- this wave's part of W_hh: MFMA step j of chunk c stands for k = w 3H/4 + 8c + 4 (lane >> 5) + j ----------
+    float wreg[NCR][2][4];
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.w_hh, (long)3 * H * H * 4);
+        const int wbase = ((wave * KW + 4 * lk) * H + u0 + lrow) * 4;
+        float4 *wl = reinterpret_cast<float4 *>(lds + kRingF) + wave * (NCL * 2 * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ld1(rs_w, wbase + ((8 * c + j) * H + 32 * ub) * 4, 0);
+                if (c < NCR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wreg[c < NCR ? c : 0][ub][j] = v[j];
+                } else {
+                    wl[((c - NCR) * 2 + ub) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- what this thread owns after the partial sums have met: rows 8w + 4 (lane >> 5) + j of each half, units
+    //      lrow and 32 + lrow of the tile (element e = 4 ub + j) ---------------------------------------------------
+    int rowoff[2][4], va[2][4];
+    unsigned inside = 0;      // bit 4h + j: the row is inside the batch
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 32 * h + 8 * wave + 4 * lk + j;
+            rowoff[h][j] = min(m, B - 1) * H * 4;                                // bytes inside one step's (B, H) block
+            inside |= (m < B ? 1u : 0u) << (4 * h + j);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // load instruction i of a slot: rows 8i .. 8i+7, eight 16-byte pieces each
+            const int r = 8 * i + (lane >> 3), p = lane & 7;
+            const int c = (p - (r >> 1)) & 7;                                    // the piece that belongs at LDS position p
+            va[h][i] = (min(m0 + 32 * h + r, B - 1) * 4 * H + 4 * c) * 4;
+        }
+    }
+    const int ucol = (u0 + lrow) * 4;
+    const int dy_bt = a.dymap.mode == 1;
+    const bool dy_ext = a.dy_ext != nullptr;      // (a call with both dy tensors goes to the 128 x 32 kernel)
+    // d_{t+1} * z_{t+1}; starts as the gradient of the final state (steps past a sequence's end pass it on unchanged)
+    float cin[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            cin[h][e] = a.dh_n ? a.dh_n[(long)(rowoff[h][e & 3] >> 2) + u0 + lrow + 32 * (e >> 2)] : 0.f;
+    float sums[2][4];      // column sums of the four gate gradients over this thread's rows, all steps, per unit block
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sums[ub][q] = 0.f;
+    const int t_last = a.dh0 ? -1 : 0;
+    PSTAMP_DECL
+
+    for (int t = T - 1; t >= t_last; --t) {
+        const int tc = max(t, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            PSTAMP(7);
+            // operands of the gate arithmetic of (step t, half h), requested before the wait and the product
+            float gr[8], gz[8], gn[8], ghn[8], hp[8], dy[8];
+            {
+                const float *gt = a.gates + (long)tc * B * H;
+                const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
+                                             rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
+                const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
+                const bool bt = dy_ext && dy_bt;
+                const __amdgpu_buffer_rsrc_t rs_d =
+                    dy_ext ? rsrc_of(a.dy_ext + (bt ? (long)tc * H : (long)tc * B * H), bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes)
+                           : rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ro = rowoff[h][e & 3], o = ro + ucol, sb = 128 * (e >> 2);
+                    gr[e] = ld1(rs_r, o, sb); gz[e] = ld1(rs_z, o, sb);
+                    gn[e] = ld1(rs_n, o, sb); ghn[e] = ld1(rs_h, o, sb);
+                    hp[e] = ld1(rs_hp, o, sb);
+                    dy[e] = ld1(rs_d, bt ? ro * T + ucol : o, sb);
+                }
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ub][r] = 0.f;
+            float val[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = 0.f;
+
+            PSTAMP(0);
+            if (t < T - 1) {
+                if (lane == 0) poll_peers(cnt + h, (unsigned)(NT * (T - 1 - t)), s.err, s.spin_limit);
+                asm volatile("" ::: "memory");
+                PSTAMP(1);
+                // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows of this half
+                const u32x4 rs_dg = res::desc_words(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
+                auto issue = [&](int st) {
+                    const int k0 = wave * KW + st * KS;
+                    const int kcol = k0 < 2 * H ? k0 : k0 + H;
+                    const unsigned dst = ring_addr + (unsigned)((st % NS) * 4096);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res::dma16_sc1(rs_dg, dst + i * 1024, va[h][i], kcol * 4);
+                };
+#pragma unroll
+                for (int d = 0; d < NS - 1; ++d)
+                    if (d < NST) issue(d);
+                // a chunk's operand reads (the dg fragment; the W_hh values of a chunk that lives in LDS) are issued
+                // one chunk ahead of its products
+                auto frag = [&](int c) {
+                    const float *slot = ring + ((c / CPS) % NS) * 1024;
+                    return *reinterpret_cast<const float4 *>(slot + lrow * 32 + 4 * rot<32>(2 * (c % CPS) + lk, lrow));
+                };
+                res::wait_loads(4 * (NST - 1 < NS - 2 ? NST - 1 : NS - 2));
+                asm volatile("" ::: "memory");
+                float4 av = frag(0), wl0 = make_float4(0.f, 0.f, 0.f, 0.f), wl1 = wl0;
+                if (NCR == 0) { wl0 = Wl[0]; wl1 = Wl[64]; }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {      // chunk: eight k, four per lane half
+                    const int st = c / CPS, cc = c % CPS;
+                    // The scheduling barriers keep this order: products of chunk c - 1 | request, count | reads of
+                    // chunk c + 1 | products of chunk c.  The slot a request overwrites was read by stage st - 1, and
+                    // the last of those reads was waited for by the products of chunk c - 1.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (cc == 0 && st + NS - 1 < NST) issue(st + NS - 1);
+                    if (cc == CPS - 1 && st + 1 < NST) {
+                        res::wait_loads(4 * (NST - 2 - st < NS - 2 ? NST - 2 - st : NS - 2));
+                        asm volatile("" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float4 b0, b1;
+                    if (c < NCR) {
+                        const int cr = c < NCR ? c : 0;
+                        b0 = make_float4(wreg[cr][0][0], wreg[cr][0][1], wreg[cr][0][2], wreg[cr][0][3]);
+                        b1 = make_float4(wreg[cr][1][0], wreg[cr][1][1], wreg[cr][1][2], wreg[cr][1][3]);
+                    } else {
+                        b0 = wl0; b1 = wl1;
+                    }
+                    const float4 a4 = av;
+                    if (c + 1 < NC) {
+                        av = frag(c + 1);
+                        if (c + 1 >= NCR) { wl0 = Wl[((c + 1 - NCR) * 2 + 0) * 64]; wl1 = Wl[((c + 1 - NCR) * 2 + 1) * 64]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (the next chunk's reads stay ahead of this chunk's products)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+                }
+                PSTAMP(2);
+                // the four partial sums meet: group v of an accumulator (registers 4v .. 4v+3: rows 8v + 4 lk + j)
+                // goes to wave v, which adds the four sources in wave order
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int ub = 0; ub < 2; ++ub)
+                        X[((v * 4 + wave) * 2 + ub) * 64 + lane] =
+                            make_float4(acc[ub][4 * v], acc[ub][4 * v + 1], acc[ub][4 * v + 2], acc[ub][4 * v + 3]);
+                __syncthreads();
+#pragma unroll
+                for (int src = 0; src < 4; ++src)
+#pragma unroll
+                    for (int ub = 0; ub < 2; ++ub) {
+                        const float4 p = X[((wave * 4 + src) * 2 + ub) * 64 + lane];
+                        val[4 * ub] += p.x; val[4 * ub + 1] += p.y; val[4 * ub + 2] += p.z; val[4 * ub + 3] += p.w;
+                    }
+                PSTAMP(3);
+            }
+
+            if (t < 0) {   // gradient of the initial state
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = m0 + 32 * h + 8 * wave + 4 * lk + (e & 3);
+                    if (m < B) a.dh0[(long)m * H + u0 + lrow + 32 * (e >> 2)] = cin[h][e] + val[e];
+                }
+                __syncthreads();      // (X is rewritten by the other half's product)
+            } else {
+                const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(a.dg + (long)t * B * 4 * H, step_bytes);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ub = e >> 2, j = e & 3;
+                    const bool active = t < Ls[32 * h + 8 * wave + 4 * lk + j];
+                    const float dhc = cin[h][e] + val[e];
+                    const float d = active ? dy[e] + dhc : 0.f;
+                    const float dn = d * (1.f - gz[e]);
+                    const float dzz = d * (hp[e] - gn[e]);
+                    const float an = active ? dn * (1.f - gn[e] * gn[e]) : 0.f;
+                    const float dar = active ? an * ghn[e] * gr[e] * (1.f - gr[e]) : 0.f;
+                    const float daz = active ? dzz * gz[e] * (1.f - gz[e]) : 0.f;
+                    const float dgn = active ? an * gr[e] : 0.f;
+                    cin[h][e] = active ? d * gz[e] : dhc;
+                    // (lanes 0-31 and 32-63 each write one whole 128-byte line per store instruction)
+                    // (dg rows are 4H wide; a row past the batch: an offset beyond the block, the stores are dropped)
+                    const int o = ((inside >> (4 * h + j)) & 1u) ? 4 * rowoff[h][j] + ucol : 0x7fffffff, sb = 128 * ub;
+                    res::st1_sc1(rs_o, o, sb, dar); res::st1_sc1(rs_o, o, sb + H * 4, daz);
+                    res::st1_sc1(rs_o, o, sb + 2 * H * 4, an); res::st1_sc1(rs_o, o, sb + 3 * H * 4, dgn);
+                    sums[ub][0] += dar; sums[ub][1] += daz; sums[ub][2] += an; sums[ub][3] += dgn;
+                }
+                PSTAMP(4);
+                if (t > t_last) arrive(cnt + h);      // (also keeps X from being rewritten before every wave has read it)
+                else __syncthreads();
+                PSTAMP(5);
+            }
+        }
+    }
+    PSTAMP_FLUSH(8)
+
+    // bias partial sums: one row per block of 32 sequences is expected; this tile's two blocks give their sum in the
+    // first row and zeros in the second.  Lane halves by shuffle, waves through LDS in wave order.
+    __syncthreads();
+    float *Xf = reinterpret_cast<float *>(X);
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = sums[ub][q] + __shfl_xor(sums[ub][q], 32);
+            if (lk == 0) Xf[((wave * 2 + ub) * 4 + q) * 32 + lrow] = v;
+        }
+    __syncthreads();
+    if (wave == 0) {
+        const int ub = lk, col = lrow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += Xf[((w * 2 + ub) * 4 + q) * 32 + col];
+            float *p = a.db_part + (long)(mt * 2) * 4 * H + q * H + u0 + 32 * ub + col;
+            p[0] = v;
+            p[4 * H] = 0.f;
+        }
+    }
+}
+
 }  // namespace
 
 // (32-bit element offsets inside one step's rows: B * 4H must stay below 2^31)
@@ -1719,8 +2047,8 @@ static int persist_row_tiles(int nt) {
     return per_xcd >= nt ? 8 * (per_xcd / nt) : 0;
 }
 
-// (one word per row tile of the finest tiling, the backward kernel's 64-sequence tiles; word 0 is unused)
-size_t gru_step_sync_words(int B) { return 1 + 2 * (size_t)((B + kRows - 1) / kRows); }
+// (one word per arrival counter of the finest tiling, the backward kernels' blocks of 32 sequences; word 0 is unused)
+size_t gru_step_sync_words(int B) { return 1 + 4 * (size_t)((B + kRows - 1) / kRows); }
 
 // (the persistent kernels address one step's rows through 32-bit buffer offsets: the largest block, a step's
 // rows of dg, must stay below 2 GiB)
@@ -1874,12 +2202,15 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hi
                 k.b = a;
                 k.sync = sync;
                 k.err = err;
-            k.err = err;
                 k.mt0 = mt0;
                 k.MT = min(per2, MT2 - mt0);
                 k.mtx = (k.MT + 7) / 8;
                 k.spin_limit = switches().spin_limit;
-                TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                const bool resident = !switches().no_step_res;      // W_hh tile resident: H a multiple of 128 up to 512
+                if (resident && a.H == 512) TGRU_LAUNCH((gru_persist_bwd_res_kernel<512, 9>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                else if (resident && a.H == 384) TGRU_LAUNCH((gru_persist_bwd_res_kernel<384, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                else if (resident && a.H == 256) TGRU_LAUNCH((gru_persist_bwd_res_kernel<256, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                else TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
             }
             return hipGetLastError();
         }

@@ -21,6 +21,7 @@ void Switches::read() {
     no_persist = on("TGRU_NO_PERSIST");
     no_step_dma = on("TGRU_NO_STEP_DMA");
     no_step_fuse = on("TGRU_NO_STEP_FUSE");
+    no_step_res = on("TGRU_NO_STEP_RES");
     step_bwd_wide = on("TGRU_STEP_BWD_WIDE");
     no_h24 = on("TGRU_NO_H24");
     no_rows = on("TGRU_NO_ROWS");
@@ -89,6 +90,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   TGRU_NO_PERSIST=1     H > 128: one launch per time step instead of the persistent kernels (gru_step.hip)
 //   TGRU_NO_STEP_DMA=1    H > 128: persistent kernels with register-staged operand tiles instead of loader waves
 //   TGRU_NO_STEP_FUSE=1   H > 128: the layer's input projection as a batched GEMM instead of inside the forward kernel
+//   TGRU_NO_STEP_RES=1    H = 256 / 384 / 512: backward recurrence with streamed W_hh tiles (64 x 64) instead of resident ones
 //   TGRU_STEP_BWD_WIDE=1  H > 128: backward persistent kernel on 128-sequence x 32-unit tiles instead of 64 x 64
 //   TGRU_SPIN_LIMIT=n     H > 128: polls after which a wait of a persistent kernel gives up (default 2^24)
 //   TGRU_NO_H24=1         generic small-H MFMA kernels at 16 < H <= 24 (gru_small.hip instead of gru_h24.hip)

@@ -21,7 +21,7 @@ extern std::atomic<unsigned long long> g_launches;
 // Kernel-family switches from the environment (TGRU_* variables), read once per process; read() reads
 // them again.
 struct Switches {
-    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, no_step_fuse, step_bwd_wide, no_wide_head;
+    bool force_generic, no_vec, no_mid, no_step, no_persist, no_h24, no_rows, no_fuse, gemm_guarded, gemm_no_dma, no_step_dma, no_step_fuse, no_step_res, step_bwd_wide, no_wide_head;
     int spin_limit;     // polls after which a wait of the persistent H > 128 kernels gives up (TGRU_SPIN_LIMIT)
     void read();
     Switches() { read(); }
