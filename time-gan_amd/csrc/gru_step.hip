@@ -1716,14 +1716,24 @@ constexpr int kSlots = TGRU_RES_SLOTS;      // ring slots per wave: one being re
 constexpr int KS = 32;                      // k per slot: 32 rows x 32 k = 4 KiB = four load instructions of a wave
 __device__ __forceinline__ void wait_loads(int n) {      // (n is a constant once the stage loop is unrolled)
     switch (n) {
+    case 24: pd::wait_vmcnt<24>(); break;
+    case 20: pd::wait_vmcnt<20>(); break;
+    case 16: pd::wait_vmcnt<16>(); break;
     case 12: pd::wait_vmcnt<12>(); break;
     case 8: pd::wait_vmcnt<8>(); break;
     case 4: pd::wait_vmcnt<4>(); break;
     default: pd::wait_vmcnt<0>(); break;
     }
 }
-__device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, sbase, kAuxSc1);
+// (write-through stores of 16 bytes: a 4-byte one costs six times as much per byte)
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int sbase, float4 f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, sbase, kAuxSc1);
+}
+__device__ __forceinline__ float4 ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, TGRU_STREAM_AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 // A direct-to-LDS load the compiler does not know to be one.  A wave of this kernel both requests its operand
 // tiles and reads them back, and the compiler makes every LDS read that follows a direct-to-LDS load it knows of
@@ -1749,11 +1759,10 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     constexpr int kR = 64, kU = 64;
     constexpr int KW = 3 * H / 4, NC = KW / 8, NCR = NC - NCL;          // a wave's k range, in chunks of eight
     constexpr int KS = res::KS, NST = KW / KS, CPS = KS / 8, NS = res::kSlots;
-    static_assert(H % 128 == 0 && KW % KS == 0 && NCL >= 0 && NCL < NC && NS >= 2 && NS <= 4, "shape");
+    static_assert(H % 128 == 0 && KW % KS == 0 && NCL >= 0 && NCL < NC && NS >= 2 && NS <= 4 && NST > NS, "shape");
     constexpr int kRingF = 4 * NS * 1024, kWlF = 4 * NCL * 2 * 256, kXF = 16 * 2 * 256;       // floats
-    static_assert((kRingF + kWlF + kXF) * 4 + kR * 4 <= 160 * 1024, "LDS");
+    static_assert((kRingF + kWlF + kXF) * 4 <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) float lds[kRingF + kWlF + kXF];
-    __shared__ int Ls[kR];         // length of each sequence of the row tile (0 for rows past the batch)
     int mt, nt;
     if (!tile_of(s.MT, s.mtx, mt, nt)) return;
     mt += s.mt0;
@@ -1770,8 +1779,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     const unsigned ring_addr = (unsigned)(unsigned long)(lds_void *)ring;      // (LDS byte address, same in every lane)
     const float4 *Wl = reinterpret_cast<const float4 *>(lds + kRingF) + wave * (NCL * 2 * 64) + lane;
     float4 *X = reinterpret_cast<float4 *>(lds + kRingF + kWlF);        // [owner wave][source wave][unit block][lane]
-
-    if (tid < kR) Ls[tid] = m0 + tid < B ? (a.lengths ? a.lengths[m0 + tid] : T) : 0;
+    const float *Xf = lds + kRingF + kWlF;
 
     // ---- this wave's part of W_hh: MFMA step j of chunk c stands for k = w 3H/4 + 8c + 4 (lane >> 5) + j ----------
     float wreg[NCR][2][4];
@@ -1796,17 +1804,19 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     }
     __syncthreads();
 
-    // ---- what this thread owns after the partial sums have met: rows 8w + 4 (lane >> 5) + j of each half, units
-    //      lrow and 32 + lrow of the tile (element e = 4 ub + j) ---------------------------------------------------
-    int rowoff[2][4], va[2][4];
-    unsigned inside = 0;      // bit 4h + j: the row is inside the batch
+    // ---- what this thread owns once the partial sums have met: of each half, rows tid/16 and 16 + tid/16, units
+    //      4 (tid % 16) .. + 3 of the tile (16-byte loads and stores, 256 contiguous bytes per 16 lanes) -----------
+    const int cg = tid & 15, er = tid >> 4;
+    int rowoff[2][2], len[2][2], va[2][4], xoff[2];
+    unsigned inside = 0;      // bit 2h + i: the row is inside the batch
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + 32 * h + 8 * wave + 4 * lk + j;
-            rowoff[h][j] = min(m, B - 1) * H * 4;                                // bytes inside one step's (B, H) block
-            inside |= (m < B ? 1u : 0u) << (4 * h + j);
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 32 * h + 16 * i + er;
+            rowoff[h][i] = min(m, B - 1) * H * 4;                                // bytes inside one step's (B, H) block
+            inside |= (m < B ? 1u : 0u) << (2 * h + i);
+            len[h][i] = m < B ? (a.lengths ? a.lengths[m] : T) : 0;              // (0: a row past the batch is never active)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // load instruction i of a slot: rows 8i .. 8i+7, eight 16-byte pieces each
@@ -1815,82 +1825,112 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
             va[h][i] = (min(m0 + 32 * h + r, B - 1) * 4 * H + 4 * c) * 4;
         }
     }
-    const int ucol = (u0 + lrow) * 4;
+    // where the partial sums of (row 16 i + er, unit 4 cg + q) lie in X: owner wave row / 8, lane 32 ((row / 4) & 1) +
+    // unit % 32, component row % 4, unit block cg / 8 -- as a float index, without the source wave's part
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + er;
+        xoff[i] = ((((row >> 3) * 4) * 2 + (cg >> 3)) * 64 + 32 * ((row >> 2) & 1) + 4 * (cg & 7)) * 4 + (row & 3);
+    }
+    const int ucol = (u0 + 4 * cg) * 4;
     const int dy_bt = a.dymap.mode == 1;
     const bool dy_ext = a.dy_ext != nullptr;      // (a call with both dy tensors goes to the 128 x 32 kernel)
     // d_{t+1} * z_{t+1}; starts as the gradient of the final state (steps past a sequence's end pass it on unchanged)
-    float cin[2][8];
+    float4 cin[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            cin[h][e] = a.dh_n ? a.dh_n[(long)(rowoff[h][e & 3] >> 2) + u0 + lrow + 32 * (e >> 2)] : 0.f;
-    float sums[2][4];      // column sums of the four gate gradients over this thread's rows, all steps, per unit block
+        for (int i = 0; i < 2; ++i)
+            cin[h][i] = a.dh_n ? *reinterpret_cast<const float4 *>(a.dh_n + (long)(rowoff[h][i] >> 2) + u0 + 4 * cg)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sums[4];      // column sums of the four gate gradients over this thread's rows, all steps: [gate].unit
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sums[ub][q] = 0.f;
+    for (int q = 0; q < 4; ++q) sums[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int t_last = a.dh0 ? -1 : 0;
     PSTAMP_DECL
 
+    // The work goes slice by slice -- (T-1, half 0), (T-1, half 1), (T-2, half 0), ... -- and the END of a slice
+    // prepares the next one, between the moment its own stores are issued and the moment they have drained:
+    // the next slice's peers are looked up (their arrival is a slice old: the counter was read under this
+    // slice's products) and its first operand tiles are requested; then ONE counted wait covers the stores of this
+    // slice (vector-memory operations complete in issue order), and the arrival for this slice follows.  The
+    // operands of a slice's gate arithmetic are requested when its product ends and arrive while the partial sums
+    // meet: held through the product they would cost 48 of the registers W_hh lives in.
+    float4 gr[2], gz[2], gn[2], ghn[2], hp[2], dy[2];      // operands of the gate arithmetic of this slice
+    auto load_operands = [&](int tt, auto hh) {
+        constexpr int h = decltype(hh)::value;
+        const int tc = max(tt, 0);
+        const float *gt = a.gates + (long)tc * B * H;
+        const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
+                                     rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
+        const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
+        // the gradient of this layer's output: the caller's dy (top layer; batch-major: the block of step tc starts
+        // tc rows in and its sequences are T rows apart) or the layer above's input gradient
+        const bool bt = dy_ext && dy_bt;
+        const __amdgpu_buffer_rsrc_t rs_d =
+            dy_ext ? rsrc_of(a.dy_ext + (bt ? (long)tc * H : (long)tc * B * H), bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes)
+                   : rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ro = rowoff[h][i], o = ro + ucol;
+            gr[i] = res::ld4(rs_r, o); gz[i] = res::ld4(rs_z, o);
+            gn[i] = res::ld4(rs_n, o); ghn[i] = res::ld4(rs_h, o);
+            hp[i] = res::ld4(rs_hp, o);
+            dy[i] = res::ld4(rs_d, bt ? ro * T + ucol : o);
+        }
+    };
+    // request stage st of the product of (step tt, half h): A = (da_r | da_z | da_n*r) of step tt+1, columns [0,2H)
+    // and [3H,4H) of the dg rows of the half
+    auto issue = [&](int tt, auto hh, int st) {
+        constexpr int h = decltype(hh)::value;
+        const u32x4 rs_dg = res::desc_words(a.dg + (long)(tt + 1) * B * 4 * H, step_bytes);
+        const int k0 = wave * KW + st * KS;
+        const int kcol = k0 < 2 * H ? k0 : k0 + H;
+        const unsigned dst = ring_addr + (unsigned)((st % NS) * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res::dma16_sc1(rs_dg, dst + i * 1024, va[h][i], kcol * 4);
+    };
+    // everything the slice (tt, half h) needs before its product can start; returns the number of vector-memory
+    // operations it issued (all younger than the stores of the slice that ends)
+    auto prepare = [&](int tt, auto hh, bool peers_in) -> int {
+        constexpr int h = decltype(hh)::value;
+        if (tt < T - 1) {
+            if (lane == 0 && !peers_in) poll_peers(cnt + h, (unsigned)(NT * (T - 1 - tt)), s.err, s.spin_limit);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int d = 0; d < NS - 1; ++d) issue(tt, hh, d);
+            return 4 * (NS - 1);
+        }
+        return 0;
+    };
+    const std::integral_constant<int, 0> h0c{};
+    const std::integral_constant<int, 1> h1c{};
+    prepare(T - 1, h0c, true);
+
     for (int t = T - 1; t >= t_last; --t) {
-        const int tc = max(t, 0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             PSTAMP(7);
-            // operands of the gate arithmetic of (step t, half h), requested before the wait and the product
-            float gr[8], gz[8], gn[8], ghn[8], hp[8], dy[8];
-            {
-                const float *gt = a.gates + (long)tc * B * H;
-                const __amdgpu_buffer_rsrc_t rs_r = rsrc_of(gt, bh_bytes), rs_z = rsrc_of(gt + plane, bh_bytes),
-                                             rs_n = rsrc_of(gt + 2 * plane, bh_bytes), rs_h = rsrc_of(gt + 3 * plane, bh_bytes);
-                const __amdgpu_buffer_rsrc_t rs_hp = rsrc_opt(tc > 0 ? a.y_int + (long)(tc - 1) * B * H : a.h0, bh_bytes);
-                const bool bt = dy_ext && dy_bt;
-                const __amdgpu_buffer_rsrc_t rs_d =
-                    dy_ext ? rsrc_of(a.dy_ext + (bt ? (long)tc * H : (long)tc * B * H), bt ? ((long)(B - 1) * T + 1) * H * 4 : bh_bytes)
-                           : rsrc_opt(a.dy_int ? a.dy_int + (long)tc * B * H : nullptr, bh_bytes);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ro = rowoff[h][e & 3], o = ro + ucol, sb = 128 * (e >> 2);
-                    gr[e] = ld1(rs_r, o, sb); gz[e] = ld1(rs_z, o, sb);
-                    gn[e] = ld1(rs_n, o, sb); ghn[e] = ld1(rs_h, o, sb);
-                    hp[e] = ld1(rs_hp, o, sb);
-                    dy[e] = ld1(rs_d, bt ? ro * T + ucol : o, sb);
-                }
-            }
             f32x16 acc[2];
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ub][r] = 0.f;
-            float val[8];
+            float4 val[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = 0.f;
+            for (int i = 0; i < 2; ++i) val[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool peers_in = false;      // the next slice's peers had all arrived when this slice's product was half done
 
             PSTAMP(0);
             if (t < T - 1) {
-                if (lane == 0) poll_peers(cnt + h, (unsigned)(NT * (T - 1 - t)), s.err, s.spin_limit);
-                asm volatile("" ::: "memory");
-                PSTAMP(1);
-                // A = (da_r | da_z | da_n*r) of step t+1: columns [0,2H) and [3H,4H) of the dg rows of this half
-                const u32x4 rs_dg = res::desc_words(a.dg + (long)(t + 1) * B * 4 * H, step_bytes);
-                auto issue = [&](int st) {
-                    const int k0 = wave * KW + st * KS;
-                    const int kcol = k0 < 2 * H ? k0 : k0 + H;
-                    const unsigned dst = ring_addr + (unsigned)((st % NS) * 4096);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) res::dma16_sc1(rs_dg, dst + i * 1024, va[h][i], kcol * 4);
-                };
-#pragma unroll
-                for (int d = 0; d < NS - 1; ++d)
-                    if (d < NST) issue(d);
+                unsigned seen = 0;
                 // a chunk's operand reads (the dg fragment; the W_hh values of a chunk that lives in LDS) are issued
                 // one chunk ahead of its products
                 auto frag = [&](int c) {
                     const float *slot = ring + ((c / CPS) % NS) * 1024;
                     return *reinterpret_cast<const float4 *>(slot + lrow * 32 + 4 * rot<32>(2 * (c % CPS) + lk, lrow));
                 };
-                res::wait_loads(4 * (NST - 1 < NS - 2 ? NST - 1 : NS - 2));
+                res::wait_loads(4 * (NS - 2));
                 asm volatile("" ::: "memory");
                 float4 av = frag(0), wl0 = make_float4(0.f, 0.f, 0.f, 0.f), wl1 = wl0;
                 if (NCR == 0) { wl0 = Wl[0]; wl1 = Wl[64]; }
@@ -1901,8 +1941,14 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                     // chunk c + 1 | products of chunk c.  The slot a request overwrites was read by stage st - 1, and
                     // the last of those reads was waited for by the products of chunk c - 1.
                     __builtin_amdgcn_sched_barrier(0);
-                    if (cc == 0 && st + NS - 1 < NST) issue(st + NS - 1);
+                    if (cc == 0 && st == NST / 2)      // (one more load in flight: the counts below wait a little longer)
+                        seen = __hip_atomic_load(cnt + (1 - h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cc == 0 && st + NS - 1 < NST) {
+                        if (h == 0) issue(t, h0c, st + NS - 1);
+                        else issue(t, h1c, st + NS - 1);
+                    }
                     if (cc == CPS - 1 && st + 1 < NST) {
+                        // stage st + 1 has landed when only the stages requested after it are still in flight
                         res::wait_loads(4 * (NST - 2 - st < NS - 2 ? NST - 2 - st : NS - 2));
                         asm volatile("" ::: "memory");
                     }
@@ -1931,8 +1977,13 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
                 }
                 PSTAMP(2);
+                if (h == 0) load_operands(t, h0c);
+                else load_operands(t, h1c);
+                // (looked at here, ahead of this slice's stores: the wait for the counter's value is over by now)
+                peers_in = seen >= (unsigned)(NT * (T - 1 - (h == 0 ? t : t - 1)));
+                asm volatile("" :: "v"(seen));
                 // the four partial sums meet: group v of an accumulator (registers 4v .. 4v+3: rows 8v + 4 lk + j)
-                // goes to wave v, which adds the four sources in wave order
+                // goes to wave v's part of X; a thread then adds the four sources of its own elements in wave order
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -1943,71 +1994,97 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
 #pragma unroll
                 for (int src = 0; src < 4; ++src)
 #pragma unroll
-                    for (int ub = 0; ub < 2; ++ub) {
-                        const float4 p = X[((wave * 4 + src) * 2 + ub) * 64 + lane];
-                        val[4 * ub] += p.x; val[4 * ub + 1] += p.y; val[4 * ub + 2] += p.z; val[4 * ub + 3] += p.w;
+                    for (int i = 0; i < 2; ++i) {
+                        const float *p = Xf + xoff[i] + src * (2 * 64 * 4);
+                        val[i].x += p[0]; val[i].y += p[4]; val[i].z += p[8]; val[i].w += p[12];
                     }
                 PSTAMP(3);
+            } else {
+                if (h == 0) load_operands(t, h0c);
+                else load_operands(t, h1c);
             }
 
             if (t < 0) {   // gradient of the initial state
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = m0 + 32 * h + 8 * wave + 4 * lk + (e & 3);
-                    if (m < B) a.dh0[(long)m * H + u0 + lrow + 32 * (e >> 2)] = cin[h][e] + val[e];
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + 32 * h + 16 * i + er;
+                    const float4 c = cin[h][i], v = val[i];
+                    if (m < B)
+                        *reinterpret_cast<float4 *>(a.dh0 + (long)m * H + u0 + 4 * cg) = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
                 }
-                __syncthreads();      // (X is rewritten by the other half's product)
             } else {
                 const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(a.dg + (long)t * B * 4 * H, step_bytes);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ub = e >> 2, j = e & 3;
-                    const bool active = t < Ls[32 * h + 8 * wave + 4 * lk + j];
-                    const float dhc = cin[h][e] + val[e];
-                    const float d = active ? dy[e] + dhc : 0.f;
-                    const float dn = d * (1.f - gz[e]);
-                    const float dzz = d * (hp[e] - gn[e]);
-                    const float an = active ? dn * (1.f - gn[e] * gn[e]) : 0.f;
-                    const float dar = active ? an * ghn[e] * gr[e] * (1.f - gr[e]) : 0.f;
-                    const float daz = active ? dzz * gz[e] * (1.f - gz[e]) : 0.f;
-                    const float dgn = active ? an * gr[e] : 0.f;
-                    cin[h][e] = active ? d * gz[e] : dhc;
-                    // (lanes 0-31 and 32-63 each write one whole 128-byte line per store instruction)
+                for (int i = 0; i < 2; ++i) {
+                    const bool active = t < len[h][i];
+                    float o_r[4], o_z[4], o_a[4], o_g[4], c_new[4];
+                    const float c_[4] = {cin[h][i].x, cin[h][i].y, cin[h][i].z, cin[h][i].w};
+                    const float v_[4] = {val[i].x, val[i].y, val[i].z, val[i].w};
+                    const float r_[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w}, z_[4] = {gz[i].x, gz[i].y, gz[i].z, gz[i].w};
+                    const float n_[4] = {gn[i].x, gn[i].y, gn[i].z, gn[i].w}, g_[4] = {ghn[i].x, ghn[i].y, ghn[i].z, ghn[i].w};
+                    const float p_[4] = {hp[i].x, hp[i].y, hp[i].z, hp[i].w}, d_[4] = {dy[i].x, dy[i].y, dy[i].z, dy[i].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dhc = c_[q] + v_[q];
+                        const float d = active ? d_[q] + dhc : 0.f;
+                        const float dn = d * (1.f - z_[q]);
+                        const float dzz = d * (p_[q] - n_[q]);
+                        const float an = active ? dn * (1.f - n_[q] * n_[q]) : 0.f;
+                        o_r[q] = active ? an * g_[q] * r_[q] * (1.f - r_[q]) : 0.f;
+                        o_z[q] = active ? dzz * z_[q] * (1.f - z_[q]) : 0.f;
+                        o_a[q] = an;
+                        o_g[q] = active ? an * r_[q] : 0.f;
+                        c_new[q] = active ? d * z_[q] : dhc;
+                    }
+                    cin[h][i] = make_float4(c_new[0], c_new[1], c_new[2], c_new[3]);
+                    const float4 vr = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]), vz = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+                    const float4 vn = make_float4(o_a[0], o_a[1], o_a[2], o_a[3]), vg = make_float4(o_g[0], o_g[1], o_g[2], o_g[3]);
                     // (dg rows are 4H wide; a row past the batch: an offset beyond the block, the stores are dropped)
-                    const int o = ((inside >> (4 * h + j)) & 1u) ? 4 * rowoff[h][j] + ucol : 0x7fffffff, sb = 128 * ub;
-                    res::st1_sc1(rs_o, o, sb, dar); res::st1_sc1(rs_o, o, sb + H * 4, daz);
-                    res::st1_sc1(rs_o, o, sb + 2 * H * 4, an); res::st1_sc1(rs_o, o, sb + 3 * H * 4, dgn);
-                    sums[ub][0] += dar; sums[ub][1] += daz; sums[ub][2] += an; sums[ub][3] += dgn;
+                    const int o = ((inside >> (2 * h + i)) & 1u) ? 4 * rowoff[h][i] + ucol : 0x7fffffff;
+                    res::st4_sc1(rs_o, o, 0, vr); res::st4_sc1(rs_o, o, H * 4, vz);
+                    res::st4_sc1(rs_o, o, 2 * H * 4, vn); res::st4_sc1(rs_o, o, 3 * H * 4, vg);
+                    sums[0].x += vr.x; sums[0].y += vr.y; sums[0].z += vr.z; sums[0].w += vr.w;
+                    sums[1].x += vz.x; sums[1].y += vz.y; sums[1].z += vz.z; sums[1].w += vz.w;
+                    sums[2].x += vn.x; sums[2].y += vn.y; sums[2].z += vn.z; sums[2].w += vn.w;
+                    sums[3].x += vg.x; sums[3].y += vg.y; sums[3].z += vg.z; sums[3].w += vg.w;
                 }
-                PSTAMP(4);
-                if (t > t_last) arrive(cnt + h);      // (also keeps X from being rewritten before every wave has read it)
-                else __syncthreads();
-                PSTAMP(5);
             }
+            PSTAMP(4);
+            // the next slice: the other half of this step, or half 0 of the step before
+            int younger = 0;
+            if (h == 0) younger = prepare(t, h1c, peers_in);
+            else if (t > t_last) younger = prepare(t - 1, h0c, peers_in);
+            PSTAMP(1);
+            // this slice's stores have landed when only the requests that followed them are in flight: arrival.  The
+            // barrier also keeps X from being rewritten before every wave has read it.
+            res::wait_loads(younger);
+            asm volatile("" ::: "memory");
+            lds_barrier();
+            if (t > t_last && tid == 0) __hip_atomic_fetch_add(cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PSTAMP(5);
         }
     }
     PSTAMP_FLUSH(8)
 
     // bias partial sums: one row per block of 32 sequences is expected; this tile's two blocks give their sum in the
-    // first row and zeros in the second.  Lane halves by shuffle, waves through LDS in wave order.
-    __syncthreads();
-    float *Xf = reinterpret_cast<float *>(X);
+    // first row and zeros in the second.  The lanes that share a unit group by shuffle, the waves through LDS in
+    // wave order.
+    float *Xw = lds + kRingF + kWlF;
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float v = sums[ub][q] + __shfl_xor(sums[ub][q], 32);
-            if (lk == 0) Xf[((wave * 2 + ub) * 4 + q) * 32 + lrow] = v;
-        }
+    for (int q = 0; q < 4; ++q) {
+        float4 v = sums[q];
+        v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+        v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+        if (lane < 16) *reinterpret_cast<float4 *>(Xw + ((wave * 4 + q) * 16 + cg) * 4) = v;
+    }
     __syncthreads();
-    if (wave == 0) {
-        const int ub = lk, col = lrow;
+    if (tid < 64) {      // unit tid of the tile: the four gates
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += Xf[((w * 2 + ub) * 4 + q) * 32 + col];
-            float *p = a.db_part + (long)(mt * 2) * 4 * H + q * H + u0 + 32 * ub + col;
+            for (int w = 0; w < 4; ++w) v += Xw[(w * 4 + q) * 64 + tid];
+            float *p = a.db_part + (long)(mt * 2) * 4 * H + q * H + u0 + tid;
             p[0] = v;
             p[4 * H] = 0.f;
         }
@@ -2207,7 +2284,7 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hi
                 k.mtx = (k.MT + 7) / 8;
                 k.spin_limit = switches().spin_limit;
                 const bool resident = !switches().no_step_res;      // W_hh tile resident: H a multiple of 128 up to 512
-                if (resident && a.H == 512) TGRU_LAUNCH((gru_persist_bwd_res_kernel<512, 9>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                if (resident && a.H == 512) TGRU_LAUNCH((gru_persist_bwd_res_kernel<512, 10>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else if (resident && a.H == 384) TGRU_LAUNCH((gru_persist_bwd_res_kernel<384, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else if (resident && a.H == 256) TGRU_LAUNCH((gru_persist_bwd_res_kernel<256, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
