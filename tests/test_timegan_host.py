@@ -247,3 +247,20 @@ def test_discarded_gradients_do_not_change_the_updates_gpu(hidden):
     for k in pa:
         d = (pa[k] - pb[k]).abs()
         assert float(d.mean()) < 2e-5 and float(d.max()) < 5e-3, (k, float(d.mean()), float(d.max()))
+
+
+def test_same_weight_calls_stay_separate_from_two_gib_on():
+    """Same-weight calls are evaluated as one concatenated batch only below 2 GiB of (rows, T, width) floats: the
+    H > 128 kernels address a batch-major tensor through 32-bit offsets.  Meta tensors: no memory is touched."""
+    from timegan_amd import losses
+    T = 256
+    lens = [T] * 2048
+    h = torch.empty(2048, T, 512, device="meta")
+    assert losses._batched([h, h], lens, 512) is None                     # 4096 x 256 x 512 floats = 2 GiB
+    narrow = torch.empty(2048, T, 64, device="meta")
+    assert losses._batched([narrow, narrow], lens, 512) is None           # the network's hidden size counts
+    both = losses._batched([narrow, narrow], lens, 64)
+    assert both is not None and both[0].shape[0] == 4096 and both[2] == [2048, 2048]
+    small = torch.empty(1024, T, 512, device="meta")
+    assert losses._batched([small, small, small], [T] * 1024, 512) is not None
+    assert losses._batched([small, small], [T] * 1023 + [T - 1], 512) is None     # ragged lengths

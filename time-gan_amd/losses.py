@@ -65,12 +65,21 @@ def _batch_mean_std(v: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Te
     return c + m1, torch.sqrt(torch.clamp(m2 - m1 * m1, min=0.0))
 
 
-def _batched(inputs, t):
+# The H > 128 kernels address a batch-major (B, T, H) tensor through 32-bit byte offsets; a batched call that reaches
+# 2 GiB would leave their persistent path (one launch per time step instead), so such calls stay separate.
+_BATCHED_BYTES_LIMIT = 1 << 31
+
+
+def _batched(inputs, t, hidden=0):
     """The inputs of several same-weight calls as ONE batch, or None when lengths are ragged (a
-    concatenation of sorted length lists is not sorted): (concatenated input, its lengths, the sizes)."""
+    concatenation of sorted length lists is not sorted) or when the batch -- rows x T x the wider of the input and
+    the network's hidden size `hidden` -- would reach 2 GiB: (concatenated input, its lengths, the sizes)."""
     T = inputs[0].shape[1]
     lens = [int(v) for v in t]
     if len(inputs) == 1 or any(v != T for v in lens):
+        return None
+    rows = sum(u.shape[0] for u in inputs)
+    if rows * T * max(int(inputs[0].shape[2]), int(hidden)) * 4 >= _BATCHED_BYTES_LIMIT:
         return None
     return torch.cat(inputs, dim=0), lens * len(inputs), [u.shape[0] for u in inputs]
 
@@ -79,8 +88,8 @@ def _apply_batched(net, inputs, t):
     """net(u, t) for each u in `inputs`, evaluated as ONE call on the concatenated batch when every
     sequence has full length (rows of a batch never interact inside a network, so the results are
     those of the separate calls the reference makes, e.g. d(h), d(_h), d(_e) at TimeGANv1.py:493-495;
-    the weight gradients come out already summed).  Ragged lengths keep separate calls."""
-    both = _batched(inputs, t)
+    the weight gradients come out already summed).  Ragged lengths, and batches of 2 GiB, keep separate calls."""
+    both = _batched(inputs, t, getattr(net, "dim_hidden", 0))
     if both is None:
         return [net(u, t) for u in inputs]
     return net(both[0], both[1]).split(both[2], dim=0)
@@ -149,7 +158,7 @@ def generator_forward(emb, sup, g, d, rec, x, t, z, gamma=1.0, group=None, h=Non
     else:
         e_hat = g(z, t)
     h_sup, h_hat = _apply_batched(sup, [h, e_hat], t)
-    both = _batched([h_hat, e_hat], t)
+    both = _batched([h_hat, e_hat], t, getattr(d, "dim_hidden", 0))
     if both is None:
         x_hat = rec(h_hat, t)
         y_fake, y_fake_e = d(h_hat, t), d(e_hat, t)
