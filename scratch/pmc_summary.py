@@ -4,7 +4,7 @@ import collections, csv, json, sys
 out, wl = sys.argv[1], sys.argv[2]
 PASSES = 3        # --steps 1 --warmup 0: the pass that counts launches, one timed pass, the pass that times the halves apart
 # kernels whose streaming reads are 16 bytes per lane: gfx950 tallies those at half their bytes
-WIDE = ("gemm_kernel", "gemm_dma_kernel", "rows_gemm_kernel", "gru_mid_wgrad_kernel", "gru_mid_bwd_kernel", "gru_mid96_fwd_kernel", "gru_mid96_bwd_kernel", "gru_mid_fwd_kernel", "gru_persist_fwd_fused_kernel", "gru_persist_fwd_dma_kernel")
+WIDE = ("gemm_kernel", "gemm_dma_kernel", "rows_gemm_kernel", "gru_mid_wgrad_kernel", "gru_mid_bwd_kernel", "gru_mid96_fwd_kernel", "gru_mid96_bwd_kernel", "gru_mid_fwd_kernel", "gru_persist_fwd_fused_kernel", "gru_persist_fwd_dma_kernel", "gru_persist_bwd_res_kernel")
 DESC = {"c3": "c3 (B1024 T24 H96 L3)", "c4": "c4 (B2048 T256 H512 L3)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()

@@ -1,24 +1,26 @@
-// Recurrent part of the GRU for large hidden states (H > 128, H a multiple of 32): ONE LAUNCH PER
-// TIME STEP, the whole chip working on that step.
+// Recurrent part of the GRU for large hidden states (H > 128, H a multiple of 32), on tiles of the
+// (sequences x hidden units) plane -- 128 x 32 forward, 64 x 64 backward -- that cover 2048 sequences x 512
+// units with one workgroup per compute unit.
 //
-// Why not a persistent kernel here: with the time loop inside the kernel a workgroup must own its
-// sequences for all steps, so it needs ALL of W_hh at every step (3 MB at H = 512, far beyond LDS):
-// each workgroup streams the matrix from L2 once per step and that traffic, not the MFMA pipe, sets
-// the step time (about 80 us at H = 512 whatever the batch).  A launch per step lets a workgroup own
-// a 128-sequence x 32-unit tile instead: it reads 32 (x 3 gates) rows of W_hh and 128 rows of
-// h_{t-1}, 12.6 MFLOP for 0.45 MB, and 256 such tiles cover 2048 sequences x 512 units in one wave of
-// workgroups.  The price is a kernel boundary per step (a few microseconds against about 30).
+// A workgroup that owned its sequences for all steps AND all units would need ALL of W_hh at every step (3 MB
+// at H = 512, far beyond LDS) and stream it from the L2 once per step.  A tile needs 32 (x 3 gates) or 64 rows of
+// the matrix and the whole previous state / gate gradients of its sequences, which the other unit tiles of the
+// same row tile produce.  Kernel families, newest first (the launcher picks; each older one stays behind a
+// switch and under the same tests):
+//   * persistent, forward with the layer's input projection inside (loader waves, direct-to-LDS tiles);
+//     persistent, backward with the W_hh tile resident in registers and LDS (H = 256 / 384 / 512);
+//   * persistent with streamed tiles: the time loop inside the kernel, the workgroups of a row tile handing
+//     each other a step's rows through write-through stores and an arrival counter;
+//   * one launch per time step (no co-residency requirement).
 //
-// forward, step t:   gh = h_{t-1} . W_hh^T for the tile's r, z, n columns (v_mfma_f32_32x32x2_f32,
-//                    two LDS tile buffers fed from a register ring that holds the operand tiles of the
-//                    next kDepth products), then the gate nonlinearities, the state
-//                    update and every store of the step in the epilogue -- the three gate values of a
-//                    (sequence, unit) pair sit in the same lane and register of three accumulators.
-// backward, step t:  dh_t = dy_t + carry + dgh_{t+1} . W_hh (same tiling, K = 3H), then the gate
-//                    gradients of step t in the epilogue: dg row t, the carry d*z for step t-1 and
-//                    the running column sums for the bias gradients.
+// forward, step t:   gh = h_{t-1} . W_hh^T for the tile's r, z, n columns (v_mfma_f32_32x32x2_f32), then the gate
+//                    nonlinearities, the state update and every store of the step in the epilogue -- the three
+//                    gate values of a (sequence, unit) pair sit in the same lane and register of three accumulators.
+// backward, step t:  dh_t = dy_t + carry + dgh_{t+1} . W_hh (K = 3H), then the gate gradients of step t in the
+//                    epilogue: dg row t, the carry d*z for step t-1 and the running column sums for the bias
+//                    gradients.
 // Workgroups are numbered so that the tiles of one XCD (every eighth workgroup) share their rows of
-// h / dg: the XCD's L2 then holds those rows plus W_hh.
+// h / dg: the XCD's L2 then holds those rows plus W_hh, and a row tile's hand-off stays inside one L2.
 #include "tgru_internal.h"
 #include <stdlib.h>
 
