@@ -21,7 +21,8 @@ backward, timed with HIP events on the launch stream) against the bound of the w
 H = 24, fp32 MFMA FLOPs for H >= 96.  `cpu_baseline` times the operator the reference itself calls
 (torch.nn.GRU on CPU behind pack_padded_sequence) on the host cores of the same box, on a bounded sample of
 the same workload, median of five steps per thread count; CPU model and core counts are stated.
-If anything after the headline measurement stalls past TGRU_BENCH_DEADLINE seconds (default 600), rank 0
+If anything after the headline measurement stalls past TGRU_BENCH_DEADLINE seconds (default 600; 240 with several
+ranks), rank 0
 prints the line with what has been measured and `"stalled": true`, and every rank exits with status 3.
 """
 import os
@@ -397,9 +398,9 @@ def child_graph_probe(backend, rank, world, joint):
     rank where this was written, so every rank runs it in a CHILD process (the children form their own
     process group on the next port): whatever happens there, the parent still reports what it has
     measured.  Two GPU processes per rank while it runs, so wide jobs skip it unless asked."""
-    if world > 4 and os.environ.get("TGRU_BENCH_DP_GRAPH") != "1":
-        joint["hipgraph_note"] = ("graph-mode data-parallel probe skipped at %d ranks "
-                                  "(set TGRU_BENCH_DP_GRAPH=1 to run it)" % world)
+    if os.environ.get("TGRU_BENCH_DP_GRAPH") != "1":
+        joint["hipgraph_note"] = ("graph-mode data-parallel probe not run at %d ranks (a second process per GPU with a "
+                                  "communicator of its own; set TGRU_BENCH_DP_GRAPH=1 to run it)" % world)
         return
     env = dict(os.environ, TGRU_BENCH_CHILD="1",
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29541")) + 17))
@@ -705,22 +706,38 @@ def main():
     def give_up():
         if rank == 0 and out is not None:
             out["stalled"] = True
-            out["stalled_note"] = "cut off at the deadline; the figures present were measured before the stall"
+            out["stalled_note"] = ("cut off at the deadline; the headline and every figure present were measured "
+                                   "before the stall, which is in a secondary probe")
         emit()
         sys.stdout.flush()
         os._exit(3)
 
-    watchdog = threading.Timer(float(os.environ.get("TGRU_BENCH_DEADLINE", "600")) + (0 if rank == 0 else 5), give_up)
+    # (with several ranks the secondary probes get four minutes: the headline is what a scaling run is for)
+    limit = float(os.environ.get("TGRU_BENCH_DEADLINE", "240" if world > 1 else "600"))
+    watchdog = threading.Timer(limit + (0 if rank == 0 else 5), give_up)
     watchdog.daemon = True
     watchdog.start()
+
+    def secondary(what, fn):
+        """A secondary probe must not cost the headline: with several ranks an exception in one of them is recorded
+        in the line instead of ending the run (a single process lets it propagate: there it is a defect to see)."""
+        if world == 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001 -- whatever a collective or a probe raises
+            if rank == 0:
+                out.setdefault("secondary_errors", {})[what] = repr(e)[:300]
+            return None
 
     if not args.only:
         for name in sorted(WORKLOADS):
             if name == args.workload:
                 continue
             st, wu = SUB_STEPS[name]
-            rec = measure_workload(tg, name, st, wu, dev, dist, rank, world, do_ar)
-            if rank == 0:
+            rec = secondary(f"workloads.{name}",
+                            lambda: measure_workload(tg, name, st, wu, dev, dist, rank, world, do_ar))
+            if rank == 0 and rec is not None:
                 out["workloads"][name] = rec
 
     if not args.no_training and not args.only:
@@ -734,7 +751,8 @@ def main():
             B, T, _, H, L, _ = WORKLOADS["c2" if name == "c1" else name]
             rec = {"config": f"{TRAIN_FEATURES[name]} features, H {H}, L {L}, T {T}, batch {B} per GPU"}
             training[name] = rec
-            training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, False, rec, count=not multi)
+            secondary(f"timegan_training.{name}",
+                      lambda: training_probe(tg, dev, TRAIN_FEATURES[name], H, L, T, B, group, False, rec, count=not multi))
             if multi and args.backend != "nccl":
                 rec["hipgraph_note"] = "graph mode with collectives inside needs the RCCL backend"
             elif multi:
