@@ -1828,7 +1828,9 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
         }
     }
     // where the partial sums of (row 16 i + er, unit 4 cg + q) lie in X: owner wave row / 8, lane 32 ((row / 4) & 1) +
-    // unit % 32, component row % 4, unit block cg / 8 -- as a float index, without the source wave's part
+    // unit % 32, component row % 4, unit block cg / 8 -- as a float index, without the source wave's part.
+    // (These reads are 4-way bank conflicts, 0.5 us per slice; a slot permutation that removes them was measured:
+    // the eight per-lane addresses it needs tip the register budget into spills inside the product loop.)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 16 * i + er;
@@ -1993,6 +1995,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                         X[((v * 4 + wave) * 2 + ub) * 64 + lane] =
                             make_float4(acc[ub][4 * v], acc[ub][4 * v + 1], acc[ub][4 * v + 2], acc[ub][4 * v + 3]);
                 __syncthreads();
+                PSTAMP(6);
 #pragma unroll
                 for (int src = 0; src < 4; ++src)
 #pragma unroll
