@@ -221,6 +221,38 @@ def count_ops(fn, device_kernels):
         return f"unavailable: {type(exc).__name__}: {exc}"[:160]
 
 
+def eager_module_call(tg, dev):
+    """Host-side cost of the drop-in module in eager mode at the stock dimensions (B 128, T 24, H 24, L 3): one
+    tg.GRU forward + backward per call pair, through the C++ autograd binding (the module's default) and through
+    the ctypes binding; the kernels of a pair take about 41 us."""
+    from timegan_amd import functional
+    B, T, _, H, L, _ = WORKLOADS["c2"]
+    gru = tg.GRU(H, H, L, batch_first=True).to(dev)
+    x = torch.rand(B, T, H, device=dev, requires_grad=True)
+    gy = torch.randn(B, T, H, device=dev)
+    rec = {"config": f"tg.GRU({H}, {H}, {L}, batch_first=True) on ({B}, {T}, {H}): forward + backward, gradients reset each pair"}
+    for name, cpp in (("cpp_binding_us", True), ("ctypes_binding_us", False)):
+        if cpp and functional.cpp_op() is None:
+            rec[name] = None
+            continue
+        gru.cpp_op = cpp
+
+        def pair():
+            gru.zero_grad(set_to_none=True)
+            y, _ = gru(x)
+            y.backward(gy)
+        for _ in range(20):
+            pair()
+        torch.cuda.synchronize()
+        n = 300
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pair()
+        torch.cuda.synchronize()
+        rec[name] = round((time.perf_counter() - t0) / n * 1e6, 1)
+    return rec
+
+
 def generation_and_scoring(tg, dev, out, cpu_leg):
     """The water-quality configuration's path (6 features, T 24, H 24, 3 layers): generation = the inference path
     g(z) -> sup -> rec (TimeGANv1.py:556-570), three stack FORWARDS per sequence, and the post-hoc scorer
@@ -768,6 +800,7 @@ def main():
         c5 = {}
         out["workloads"]["c5"] = c5
         generation_and_scoring(tg, dev, c5, not args.no_cpu)
+        out["workloads"]["c2"]["eager_module_call"] = eager_module_call(tg, dev)
 
     if rank == 0 and world == 1 and not args.no_cpu:
         for name, rec in out["workloads"].items():

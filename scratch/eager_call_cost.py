@@ -9,6 +9,7 @@ gru = tg.GRU(H, H, L, batch_first=True).to(dev)
 x = torch.rand(B, T, H, device=dev, requires_grad=True)
 gy = torch.randn(B, T, H, device=dev)
 def step():
+    gru.zero_grad(set_to_none=True)      # (as a training loop does: the gradients are adopted, not added)
     y, _ = gru(x)
     y.backward(gy)
 for _ in range(20): step()

@@ -153,3 +153,16 @@ def test_no_gfx950_device_is_reported_not_launched():
     assert rc == E_NOGPU
     n0 = tg.launch_count()
     assert tg.launch_count() == n0            # nothing was launched by the rejected calls
+
+
+def test_cpp_autograd_binding_loads_and_refuses_cpu_tensors():
+    """time-gan_amd/_tgru_torch.so (csrc_torch/tgru_torch.cpp) is the torch extension over the same C ABI: it must
+    load where the library loads, and like the ctypes binding it has no CPU path."""
+    import torch
+    from timegan_amd import functional
+    mod = functional.cpp_op()
+    assert mod is not None, "time-gan_amd/_tgru_torch.so is not built (python __graft_entry__.py build)"
+    H = 8
+    w = [torch.zeros(3 * H, 4), torch.zeros(3 * H, H), torch.zeros(3 * H), torch.zeros(3 * H)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mod.gru_apply(torch.zeros(2, 3, 4), None, None, None, 2, 3, 1, w)

@@ -509,3 +509,57 @@ def test_frozen_weights_give_the_same_input_gradient(B, T, In, H, L):
     assert all(p.grad is not None for p in rnn.parameters())      # from the last full run only
     assert torch.equal(part[0], full[0]) and torch.equal(part[1], full[1])
     assert launches_frozen < launches_full
+
+
+@pytest.mark.parametrize("case", ["padded_lengths_h0", "time_major", "packed", "only_h_n", "frozen_weights", "no_grad"])
+def test_cpp_autograd_binding_equals_the_ctypes_binding(case):
+    """tg.GRU goes through the C++ autograd function of time-gan_amd/_tgru_torch.so by default (`cpp_op`); the same
+    module with `cpp_op = False` goes through the ctypes binding.  Both call the same C ABI with the same buffers'
+    contents, so outputs and gradients are bit-equal."""
+    import timegan_amd as tg
+    from timegan_amd import functional
+    assert functional.cpp_op() is not None, "time-gan_amd/_tgru_torch.so is not built"
+    torch.manual_seed(11)
+    B, T, In, H, L = 9, 7, 5, 24, 2
+    batch_first = case != "time_major"
+    rnn = tg.GRU(In, H, L, batch_first=batch_first).to("cuda:0")
+    if case == "frozen_weights":
+        for p_ in rnn.parameters():
+            p_.requires_grad_(False)
+    lens = [7, 7, 6, 4, 4, 3, 2, 1, 1]
+    x0 = torch.rand((B, T, In) if batch_first else (T, B, In), device="cuda:0")
+    h00 = torch.randn(L, B, H, device="cuda:0")
+    gy = torch.randn((B, T, H) if batch_first else (T, B, H), device="cuda:0")
+    gh = torch.randn(L, B, H, device="cuda:0")
+    results = []
+    for cpp in (True, False):
+        rnn.cpp_op = cpp
+        rnn.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        h0 = h00.clone().requires_grad_(True)
+        n0 = tg.launch_count()
+        if case == "no_grad":
+            with torch.no_grad():
+                y, h_n = rnn(x, h0, lengths=lens)
+            results.append([y, h_n])
+            continue
+        if case == "packed":
+            packed = nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=True)
+            yp, h_n = rnn(packed, h0)
+            y, _ = nn.utils.rnn.pad_packed_sequence(yp, batch_first=True, total_length=T)
+        elif case == "padded_lengths_h0" or case == "frozen_weights":
+            y, h_n = rnn(x, h0, lengths=lens)
+        else:
+            y, h_n = rnn(x, h0)
+        loss = (h_n * gh).sum() if case == "only_h_n" else (y * gy).sum() + (h_n * gh).sum()
+        loss.backward()
+        grads = [p_.grad for p_ in rnn.parameters()]
+        if case == "frozen_weights":
+            assert all(g is None for g in grads)
+            grads = []
+        results.append([y.detach(), h_n.detach(), x.grad, h0.grad, *grads])
+        assert tg.launch_count() > n0
+    a, b = results
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

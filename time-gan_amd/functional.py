@@ -284,16 +284,45 @@ def gru_apply_pair(call_a, call_b):
     return (ya, ha), (yb, hb)
 
 
+_cpp_state = {"tried": False, "module": None}
+
+
+def cpp_op():
+    """The C++ autograd binding of the GRU (time-gan_amd/_tgru_torch.so, built by csrc_torch/build.sh: a torch
+    extension over the same C ABI that reads the current HIP stream itself and runs its backward pass in
+    autograd's thread without entering Python), or None: not built, switched off with TGRU_NO_CPP_OP=1, or
+    another build of the library selected with TGRU_LIB_PATH (the extension is linked to the in-tree one)."""
+    if not _cpp_state["tried"]:
+        _cpp_state["tried"] = True
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tgru_torch.so")
+        if (os.path.exists(path) and os.environ.get("TGRU_NO_CPP_OP") != "1" and not os.environ.get("TGRU_LIB_PATH")):
+            lib()      # the C-ABI library first: a missing or broken libtgru.so must fail as loudly as ever
+            spec = importlib.util.spec_from_file_location("_tgru_torch", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _cpp_state["module"] = mod
+    return _cpp_state["module"]
+
+
 def gru_apply(x: torch.Tensor, weights: Sequence[torch.Tensor], B: int, T: int, layout: int,
               h0: Optional[torch.Tensor] = None, lengths: Optional[torch.Tensor] = None,
-              toff: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+              toff: Optional[torch.Tensor] = None, cpp: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Differentiable multi-layer GRU.
 
     x in `layout` ((T,B,In), (B,T,In) or packed rows); weights flat in torch's order
     [weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, weight_ih_l1, ...];
     lengths / toff: int32 device tensors (see include/tgru.h), None for full-length sequences.
+    `cpp`: go through the C++ autograd binding when it is there (same C ABI, same results; its weight gradients
+    are complete when backward returns, so callers that collect theirs in a deferred-reduction queue leave it off).
     Returns (y in the same layout, h_n (L,B,H)).
     """
+    if cpp and x.is_cuda and deferred.active() is None:
+        mod = cpp_op()
+        if mod is not None:
+            y, h_n = mod.gru_apply(x, h0, lengths, toff, B, T, layout, list(weights))
+            return y, h_n
     return _GRUFunction.apply(x, h0, lengths, toff, B, T, layout, torch.is_grad_enabled(), *weights)
 
 

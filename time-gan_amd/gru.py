@@ -17,6 +17,10 @@ from ._lib import LAYOUT_BTF, LAYOUT_PACKED, LAYOUT_TBF
 
 
 class GRU(nn.Module):
+    # Eager calls go through the C++ autograd binding when it is built (functional.cpp_op); the recurrent blocks of
+    # timegan_amd.modules switch it off for their GRUs, whose gradients go through the deferred-reduction queue.
+    cpp_op = True
+
     def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, bias: bool = True,
                  batch_first: bool = False, dropout: float = 0.0, bidirectional: bool = False,
                  device=None, dtype=None):
@@ -82,7 +86,7 @@ class GRU(nn.Module):
                 hx = hx.index_select(1, sorted_idx)
             if int(batch_sizes[-1]) == B:
                 # every sequence is full length: packed rows are exactly (T,B,In) time-major
-                y, h_n = F_.gru_apply(data.view(T, B, -1), weights, B, T, LAYOUT_TBF, h0=hx)
+                y, h_n = F_.gru_apply(data.view(T, B, -1), weights, B, T, LAYOUT_TBF, h0=hx, cpp=self.cpp_op)
                 y = y.view(T * B, H)
             else:
                 bs = batch_sizes.to(torch.int64)
@@ -90,7 +94,7 @@ class GRU(nn.Module):
                 toff = torch.zeros(T + 1, dtype=torch.int32)
                 toff[1:] = torch.cumsum(bs, 0).to(torch.int32)
                 y, h_n = F_.gru_apply(data, weights, B, T, LAYOUT_PACKED, h0=hx,
-                                      lengths=lens.to(data.device), toff=toff.to(data.device))
+                                      lengths=lens.to(data.device), toff=toff.to(data.device), cpp=self.cpp_op)
             if unsorted_idx is not None:
                 h_n = h_n.index_select(1, unsorted_idx)
             return PackedSequence(y, batch_sizes, sorted_idx, unsorted_idx), h_n
@@ -114,7 +118,7 @@ class GRU(nn.Module):
         if hx is not None and tuple(hx.shape) != (L, B, H):
             raise RuntimeError(f"Expected hidden size {(L, B, H)}, got {list(hx.shape)}")
         lens_dev = F_.lengths_to_device(lengths, B, T, input.device)
-        return F_.gru_apply(input, weights, B, T, layout, h0=hx, lengths=lens_dev)
+        return F_.gru_apply(input, weights, B, T, layout, h0=hx, lengths=lens_dev, cpp=self.cpp_op)
 
 
 def gru_pair(rnn_a: "GRU", x_a: torch.Tensor, lengths_a, rnn_b: "GRU", x_b: torch.Tensor, lengths_b):

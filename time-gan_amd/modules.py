@@ -51,6 +51,7 @@ class _RecurrentBlock(nn.Module):
 
     def _run_rnn(self, rnn: nn.Module, x: torch.Tensor, t) -> torch.Tensor:
         if isinstance(rnn, GRU):
+            rnn.cpp_op = False      # (the trainer sums these gradients through the deferred-reduction queue)
             h, _ = rnn(x, lengths=t)
             if self.padding_value != 0:
                 lens = torch.as_tensor([int(v) for v in t], device=x.device)
