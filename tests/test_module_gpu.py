@@ -304,7 +304,9 @@ def test_large_hidden_forward_with_the_projection_inside(B, T, In, H, L, ragged,
 @pytest.mark.parametrize("B,T,In,H,L,ragged,with_h0", [(300, 6, 64, 512, 2, True, True),
                                                         (2048, 3, 512, 512, 1, False, False),    # one workgroup per CU
                                                         (2500, 4, 32, 256, 2, True, True),      # several launches
-                                                        (129, 5, 96, 384, 3, False, True)])
+                                                        (129, 5, 96, 384, 3, False, True),
+                                                        (3, 2, 32, 256, 1, False, True),        # second half of the tile empty
+                                                        (70, 1, 64, 512, 2, False, True)])      # one step: dh0 only
 def test_large_hidden_backward_with_resident_recurrent_weights(B, T, In, H, L, ragged, with_h0, monkeypatch):
     """The backward recurrence that keeps its tile of W_hh in registers and LDS (waves split k and fetch their own
     operand tiles, two chains of 32 sequences per workgroup with a counter each) against the kernel that streams
