@@ -1712,19 +1712,29 @@ __global__ __launch_bounds__(pd::kThreads) void gru_persist_fwd_fused_kernel(Per
 // ----------------------------------------------------------------------------------------------
 namespace res {
 #ifndef TGRU_RES_SLOTS
-#define TGRU_RES_SLOTS 3
+#define TGRU_RES_SLOTS 4
+#endif
+#ifndef TGRU_RES_KS
+#define TGRU_RES_KS 16
+#endif
+#ifndef TGRU_RES_NCL512
+#define TGRU_RES_NCL512 12
 #endif
 constexpr int kSlots = TGRU_RES_SLOTS;      // ring slots per wave: one being read, the others in flight
-constexpr int KS = 32;                      // k per slot: 32 rows x 32 k = 4 KiB = four load instructions of a wave
+constexpr int KS = TGRU_RES_KS;             // k per slot: 32 rows x 16 k = 2 KiB = two load instructions of a wave (or 32 k: four)
+constexpr int kNcl512 = TGRU_RES_NCL512;    // chunks of W_hh a wave keeps in LDS at H = 512 (what LDS has room for)
 __device__ __forceinline__ void wait_loads(int n) {      // (n is a constant once the stage loop is unrolled)
     switch (n) {
     case 24: pd::wait_vmcnt<24>(); break;
     case 20: pd::wait_vmcnt<20>(); break;
     case 16: pd::wait_vmcnt<16>(); break;
     case 12: pd::wait_vmcnt<12>(); break;
+    case 10: pd::wait_vmcnt<10>(); break;
     case 8: pd::wait_vmcnt<8>(); break;
+    case 6: pd::wait_vmcnt<6>(); break;
     case 4: pd::wait_vmcnt<4>(); break;
-    default: pd::wait_vmcnt<0>(); break;
+    case 2: pd::wait_vmcnt<2>(); break;
+    default: pd::wait_vmcnt<0>(); break;      // (0, or a count this switch does not know: wait for everything)
     }
 }
 // (write-through stores of 16 bytes: a 4-byte one costs six times as much per byte)
@@ -1761,8 +1771,10 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     constexpr int kR = 64, kU = 64;
     constexpr int KW = 3 * H / 4, NC = KW / 8, NCR = NC - NCL;          // a wave's k range, in chunks of eight
     constexpr int KS = res::KS, NST = KW / KS, CPS = KS / 8, NS = res::kSlots;
-    static_assert(H % 128 == 0 && KW % KS == 0 && NCL >= 0 && NCL < NC && NS >= 2 && NS <= 4 && NST > NS, "shape");
-    constexpr int kRingF = 4 * NS * 1024, kWlF = 4 * NCL * 2 * 256, kXF = 16 * 2 * 256;       // floats
+    constexpr int kSlotF = 32 * KS, IPS = kSlotF / 256, Q = KS / 4;      // a slot in floats, its load instructions, pieces per row
+    static_assert((KS == 16 || KS == 32) && IPS * (NS - 1) <= 12, "stage");
+    static_assert(H % 128 == 0 && KW % KS == 0 && NCL >= 0 && NCL < NC && NS >= 2 && NS <= 6 && NST > NS, "shape");
+    constexpr int kRingF = 4 * NS * kSlotF, kWlF = 4 * NCL * 2 * 256, kXF = 16 * 2 * 256;       // floats
     static_assert((kRingF + kWlF + kXF) * 4 <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) float lds[kRingF + kWlF + kXF];
     int mt, nt;
@@ -1777,7 +1789,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     unsigned *cnt = s.sync + 1 + 2 * mt;           // [half]
     const long plane = (long)T * B * H;
     const long step_bytes = (long)B * 4 * H * 4, bh_bytes = (long)B * H * 4;
-    float *ring = lds + wave * (NS * 1024);
+    float *ring = lds + wave * (NS * kSlotF);
     const unsigned ring_addr = (unsigned)(unsigned long)(lds_void *)ring;      // (LDS byte address, same in every lane)
     const float4 *Wl = reinterpret_cast<const float4 *>(lds + kRingF) + wave * (NCL * 2 * 64) + lane;
     float4 *X = reinterpret_cast<float4 *>(lds + kRingF + kWlF);        // [owner wave][source wave][unit block][lane]
@@ -1809,7 +1821,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
     // ---- what this thread owns once the partial sums have met: of each half, rows tid/16 and 16 + tid/16, units
     //      4 (tid % 16) .. + 3 of the tile (16-byte loads and stores, 256 contiguous bytes per 16 lanes) -----------
     const int cg = tid & 15, er = tid >> 4;
-    int rowoff[2][2], len[2][2], va[2][4], xoff[2];
+    int rowoff[2][2], len[2][2], va[2][IPS], xoff[2];
     unsigned inside = 0;      // bit 2h + i: the row is inside the batch
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1821,21 +1833,24 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
             len[h][i] = m < B ? (a.lengths ? a.lengths[m] : T) : 0;              // (0: a row past the batch is never active)
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {      // load instruction i of a slot: rows 8i .. 8i+7, eight 16-byte pieces each
-            const int r = 8 * i + (lane >> 3), p = lane & 7;
-            const int c = (p - (r >> 1)) & 7;                                    // the piece that belongs at LDS position p
+        for (int i = 0; i < IPS; ++i) {      // load instruction i of a slot: 64 / Q rows of Q 16-byte pieces each
+            const int r = (64 / Q) * i + lane / Q, p = lane % Q;
+            const int c = (p - r * Q / 16) & (Q - 1);                            // the piece that belongs at LDS position p
             va[h][i] = (min(m0 + 32 * h + r, B - 1) * 4 * H + 4 * c) * 4;
         }
     }
-    // where the partial sums of (row 16 i + er, unit 4 cg + q) lie in X: owner wave row / 8, lane 32 ((row / 4) & 1) +
-    // unit % 32, component row % 4, unit block cg / 8 -- as a float index, without the source wave's part.
-    // (These reads are 4-way bank conflicts, 0.5 us per slice; a slot permutation that removes them was measured:
-    // the eight per-lane addresses it needs tip the register budget into spills inside the product loop.)
+    // where the partial sums of (row 16 i + er, unit 4 cg + q) lie in X: owner wave row / 8, unit block cg / 8,
+    // writer lane 32 ((row / 4) & 1) + unit % 32, component row % 4 -- as a float index, without the source wave's
+    // part and without q.  A writer lane's 16-byte slot is its lane number with the two low bits flipped by
+    // bit 4 of the lane and by the unit block (xq below, seen from the reading side): the 64 lanes of one read
+    // instruction -- eight unit groups x two unit blocks x four rows -- then touch 64 different banks (read
+    // straight, they are 4-way conflicts: 0.5 us per slice).
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 16 * i + er;
         xoff[i] = ((((row >> 3) * 4) * 2 + (cg >> 3)) * 64 + 32 * ((row >> 2) & 1) + 4 * (cg & 7)) * 4 + (row & 3);
     }
+    const int xq = ((cg >> 2) & 1) ^ (2 * (cg >> 3));      // unit q of this thread's group sits in slot q ^ xq
     const int ucol = (u0 + 4 * cg) * 4;
     const int dy_bt = a.dymap.mode == 1;
     const bool dy_ext = a.dy_ext != nullptr;      // (a call with both dy tensors goes to the 128 x 32 kernel)
@@ -1890,9 +1905,9 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
         const u32x4 rs_dg = res::desc_words(a.dg + (long)(tt + 1) * B * 4 * H, step_bytes);
         const int k0 = wave * KW + st * KS;
         const int kcol = k0 < 2 * H ? k0 : k0 + H;
-        const unsigned dst = ring_addr + (unsigned)((st % NS) * 4096);
+        const unsigned dst = ring_addr + (unsigned)((st % NS) * kSlotF * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) res::dma16_sc1(rs_dg, dst + i * 1024, va[h][i], kcol * 4);
+        for (int i = 0; i < IPS; ++i) res::dma16_sc1(rs_dg, dst + i * 1024, va[h][i], kcol * 4);
     };
     // everything the slice (tt, half h) needs before its product can start; returns the number of vector-memory
     // operations it issued (all younger than the stores of the slice that ends)
@@ -1903,7 +1918,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int d = 0; d < NS - 1; ++d) issue(tt, hh, d);
-            return 4 * (NS - 1);
+            return IPS * (NS - 1);
         }
         return 0;
     };
@@ -1931,10 +1946,10 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                 // a chunk's operand reads (the dg fragment; the W_hh values of a chunk that lives in LDS) are issued
                 // one chunk ahead of its products
                 auto frag = [&](int c) {
-                    const float *slot = ring + ((c / CPS) % NS) * 1024;
-                    return *reinterpret_cast<const float4 *>(slot + lrow * 32 + 4 * rot<32>(2 * (c % CPS) + lk, lrow));
+                    const float *slot = ring + ((c / CPS) % NS) * kSlotF;
+                    return *reinterpret_cast<const float4 *>(slot + lrow * KS + 4 * rot<KS>(2 * (c % CPS) + lk, lrow));
                 };
-                res::wait_loads(4 * (NS - 2));
+                res::wait_loads(IPS * (NS - 2));
                 asm volatile("" ::: "memory");
                 float4 av = frag(0), wl0 = make_float4(0.f, 0.f, 0.f, 0.f), wl1 = wl0;
                 if (NCR == 0) { wl0 = Wl[0]; wl1 = Wl[64]; }
@@ -1953,7 +1968,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                     }
                     if (cc == CPS - 1 && st + 1 < NST) {
                         // stage st + 1 has landed when only the stages requested after it are still in flight
-                        res::wait_loads(4 * (NST - 2 - st < NS - 2 ? NST - 2 - st : NS - 2));
+                        res::wait_loads(IPS * (NST - 2 - st < NS - 2 ? NST - 2 - st : NS - 2));
                         asm volatile("" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1992,7 +2007,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
                     for (int ub = 0; ub < 2; ++ub)
-                        X[((v * 4 + wave) * 2 + ub) * 64 + lane] =
+                        X[((v * 4 + wave) * 2 + ub) * 64 + (lane ^ ((lane >> 4) & 1) ^ (2 * ub))] =
                             make_float4(acc[ub][4 * v], acc[ub][4 * v + 1], acc[ub][4 * v + 2], acc[ub][4 * v + 3]);
                 __syncthreads();
                 PSTAMP(6);
@@ -2001,7 +2016,7 @@ __global__ __launch_bounds__(256) void gru_persist_bwd_res_kernel(PersistBwd s) 
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const float *p = Xf + xoff[i] + src * (2 * 64 * 4);
-                        val[i].x += p[0]; val[i].y += p[4]; val[i].z += p[8]; val[i].w += p[12];
+                        val[i].x += p[4 * xq]; val[i].y += p[4 * (1 ^ xq)]; val[i].z += p[4 * (2 ^ xq)]; val[i].w += p[4 * (3 ^ xq)];
                     }
                 PSTAMP(3);
             } else {
@@ -2289,7 +2304,7 @@ hipError_t launch_gru_step_bwd(const BwdArgs &a, float *carry, unsigned *err, hi
                 k.mtx = (k.MT + 7) / 8;
                 k.spin_limit = switches().spin_limit;
                 const bool resident = !switches().no_step_res;      // W_hh tile resident: H a multiple of 128 up to 512
-                if (resident && a.H == 512) TGRU_LAUNCH((gru_persist_bwd_res_kernel<512, 10>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
+                if (resident && a.H == 512) TGRU_LAUNCH((gru_persist_bwd_res_kernel<512, res::kNcl512>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else if (resident && a.H == 384) TGRU_LAUNCH((gru_persist_bwd_res_kernel<384, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else if (resident && a.H == 256) TGRU_LAUNCH((gru_persist_bwd_res_kernel<256, 0>), dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
                 else TGRU_LAUNCH(gru_persist_bwd_sq_kernel<64>, dim3(8 * k.mtx * NT2), dim3(256), 0, s, k);
