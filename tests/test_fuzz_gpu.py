@@ -50,6 +50,53 @@ def test_random_gru_shape_matches_torch(seed):
         assert_close(q.grad.cpu().numpy(), p.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{name} {tag}")
 
 
+def _large_case(rng):
+    H = int(rng.choice([160, 192, 256, 384, 512]))       # 256 / 384 / 512: the backward kernel with resident W_hh
+    In = int(rng.choice([20, 32, 40, 64, 96]))            # multiples of 32: the projection inside the forward kernel
+    L = int(rng.integers(1, 3))
+    T = int(rng.choice([1, 2, 3, 6]))
+    B = int(rng.choice([1, 5, 31, 33, 63, 64, 65, 130, 300]))
+    return B, T, In, H, L, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TGRU_FUZZ_SEEDS_LARGE", "16"))))
+def test_random_large_hidden_shape_matches_torch(seed):
+    """The same check on the persistent H > 128 kernels: batches that end inside a row tile or inside its first
+    half, single steps, ragged lengths, initial states, both layouts."""
+    import timegan_amd as tg
+    rng = np.random.default_rng(9000 + seed)
+    B, T, In, H, L, ragged, with_h0, batch_first = _large_case(rng)
+    torch.manual_seed(seed)
+    ref = torch.nn.GRU(In, H, num_layers=L, batch_first=batch_first)
+    ours = tg.GRU(In, H, num_layers=L, batch_first=batch_first).to("cuda:0")
+    ours.load_state_dict(ref.state_dict())
+    x = torch.rand((B, T, In) if batch_first else (T, B, In))
+    h0 = torch.randn(L, B, H) if with_h0 else None
+    lens = sorted((int(v) for v in rng.integers(1, T + 1, B)), reverse=True) if ragged else [T] * B
+    xr = x.clone().requires_grad_(True)
+    hr = None if h0 is None else h0.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=batch_first, enforce_sorted=True)
+    yp, hn_r = ref(packed, hr)
+    y_r, _ = torch.nn.utils.rnn.pad_packed_sequence(yp, batch_first=batch_first, total_length=T)
+    wy, wh = torch.randn(y_r.shape), torch.randn(hn_r.shape)
+    ((y_r * wy).sum() + (hn_r * wh).sum()).backward()
+
+    tg.persist_timeouts()
+    xo = x.clone().to("cuda:0").requires_grad_(True)
+    ho = None if h0 is None else h0.clone().to("cuda:0").requires_grad_(True)
+    y_o, hn_o = ours(xo, ho, lengths=lens)
+    ((y_o * wy.to("cuda:0")).sum() + (hn_o * wh.to("cuda:0")).sum()).backward()
+    assert tg.persist_timeouts() == 0
+    tag = f"B{B} T{T} In{In} H{H} L{L} ragged{ragged} h0{with_h0} bf{batch_first}"
+    assert_close(y_o.detach().cpu().numpy(), y_r.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "y " + tag)
+    assert_close(hn_o.detach().cpu().numpy(), hn_r.detach().numpy(), FWD_RTOL, FWD_ATOL_SCALE, "h_n " + tag)
+    assert_close(xo.grad.cpu().numpy(), xr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dx " + tag)
+    if with_h0:
+        assert_close(ho.grad.cpu().numpy(), hr.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, "dh0 " + tag)
+    for (name, p), q in zip(ref.named_parameters(), ours.parameters()):
+        assert_close(q.grad.cpu().numpy(), p.grad.numpy(), GRAD_RTOL, GRAD_ATOL_SCALE, f"{name} {tag}")
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TGRU_FUZZ_SEEDS", "24"))))
 def test_random_head_shape_matches_torch(seed):
     import copy
