@@ -78,9 +78,15 @@ extern "C" int tgru_debug_stamps_wgrad(unsigned long long *out) {
 #define WSTAMP_DECL
 #endif
 
+// The layers of a stack as one launch: blockIdx.y picks the layer (the layers' weight gradients depend on nothing a
+// later recurrence produces, so they can all wait for the last one: one launch and one reduction per stack instead
+// of one per layer).
+struct MidWgradBatch { MidWgradArgs l[kMidWgradMaxLayers]; };
+
 template <int HC>
-__global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
+__global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradBatch batch) {
     using namespace midw;
+    const MidWgradArgs &a = batch.l[blockIdx.y];
     WSTAMP_DECL
     extern __shared__ __attribute__((aligned(16))) float smem[];   // kSlots x ( as[kRows][H] | bs[kRows][W] )
     const int H = HC ? HC : a.H, In = HC ? HC : a.In, B = a.B;
@@ -256,10 +262,20 @@ __global__ __launch_bounds__(576) void gru_mid_wgrad_kernel(MidWgradArgs a) {
 // partial sums db_part (rows x 4H: da_r | da_z | da_n | da_n*r): db_ih = columns 0 .. 3H-1, db_hh = columns
 // 0 .. 2H-1 and 3H .. 4H-1; 8 columns x 32 row groups per workgroup.  (One launch for both: each alone is a
 // few microseconds of launch latency around almost no work.)
-__global__ __launch_bounds__(256) void mid_wgrad_reduce_kernel(const float *slabs, long stride, int nslabs,
-                                                               float *out_a, long na, float *out_b, long nb,
-                                                               int accumulate, int wblocks, const float *db_part,
-                                                               int db_rows, int H, float *db_ih, float *db_hh) {
+struct MidReduceArgs {
+    const float *slabs; long stride; int nslabs;
+    float *out_a; long na; float *out_b; long nb;
+    const float *db_part; int db_rows; float *db_ih, *db_hh;
+};
+struct MidReduceBatch { MidReduceArgs l[kMidWgradMaxLayers]; };
+
+__global__ __launch_bounds__(256) void mid_wgrad_reduce_kernel(MidReduceBatch batch, int accumulate, int wblocks, int H) {
+    const MidReduceArgs &q = batch.l[blockIdx.y];
+    const float *slabs = q.slabs, *db_part = q.db_part;
+    const long stride = q.stride, na = q.na, nb = q.nb;
+    const int nslabs = q.nslabs, db_rows = q.db_rows;
+    float *out_a = q.out_a, *out_b = q.out_b, *db_ih = q.db_ih, *db_hh = q.db_hh;
+    if ((int)blockIdx.x >= wblocks && !db_part) return;      // (a layer without bias partials in a batch that has some)
     __shared__ float part[256];
     const bool bias = (int)blockIdx.x >= wblocks;
     // weights: 32 elements x 8 slab groups; biases: 8 columns x 32 row groups (rows are many, columns few)
@@ -316,17 +332,31 @@ int gru_mid_wgrad_workgroups(int B, int T) {
 }
 long gru_mid_wgrad_slab_floats(int In, int H) { return 3L * H * (In + H); }
 
-hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
-                                const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
-                                int accumulate, const float *db_part, int db_rows, float *db_ih, float *db_hh,
-                                hipStream_t s) {
-    MidWgradArgs a{};
-    a.dg = dg; a.xin = xin; a.In = In; a.x_bt = x_bt; a.y = y; a.h0 = h0; a.slabs = slabs;
-    a.slab_stride = gru_mid_wgrad_slab_floats(In, H);
-    a.B = B; a.T = T; a.H = H;
+hipError_t launch_gru_mid_wgrad_batch(const MidWgradJob *jobs, int njobs_, int B, int T, int H, int accumulate,
+                                      hipStream_t s) {
+    if (njobs_ < 1 || njobs_ > kMidWgradMaxLayers) return hipErrorInvalidValue;
+    const int In = jobs[0].In;
+    for (int k = 1; k < njobs_; ++k)
+        if (jobs[k].In != In || (jobs[k].db_part != nullptr) != (jobs[0].db_part != nullptr)) return hipErrorInvalidValue;
+    MidWgradBatch wb{};
+    MidReduceBatch rb{};
     const int nchunks = gru_mid_wgrad_workgroups(B, T);
     const int K = B * T;
-    a.rows_per_chunk = ((K + nchunks - 1) / nchunks + midw::kRows - 1) / midw::kRows * midw::kRows;
+    const int rows_per_chunk = ((K + nchunks - 1) / nchunks + midw::kRows - 1) / midw::kRows * midw::kRows;
+    const int used = (K + rows_per_chunk - 1) / rows_per_chunk;     // chunks that own rows
+    const long na = 3L * H * In, nb = 3L * H * H;
+    for (int k = 0; k < njobs_; ++k) {
+        MidWgradArgs &a = wb.l[k];
+        const MidWgradJob &j = jobs[k];
+        a.dg = j.dg; a.xin = j.xin; a.In = In; a.x_bt = j.x_bt; a.y = j.y; a.h0 = j.h0; a.slabs = j.slabs;
+        a.slab_stride = gru_mid_wgrad_slab_floats(In, H);
+        a.B = B; a.T = T; a.H = H;
+        a.rows_per_chunk = rows_per_chunk;
+        a.njobs = used * midw::kJobs;
+        MidReduceArgs &q = rb.l[k];
+        q.slabs = j.slabs; q.stride = a.slab_stride; q.nslabs = used; q.out_a = j.dw_ih; q.na = na; q.out_b = j.dw_hh;
+        q.nb = nb; q.db_part = j.db_part; q.db_rows = j.db_rows; q.db_ih = j.db_ih; q.db_hh = j.db_hh;
+    }
     const int widest = In > H ? In : H;
     const bool nine = H == 96 && In == 96;              // eight waves share the ninth tile
     const int nwaves = nine ? 8 : ((H + 31) / 32) * ((widest + 31) / 32);
@@ -339,17 +369,22 @@ hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int used = (K + a.rows_per_chunk - 1) / a.rows_per_chunk;     // chunks that own rows
-    a.njobs = used * midw::kJobs;
-    if (nine) TGRU_LAUNCH(gru_mid_wgrad_kernel<96>, dim3((a.njobs + 7) / 8 * 8), dim3(64 * nwaves), lds, s, a);
-    else TGRU_LAUNCH(gru_mid_wgrad_kernel<0>, dim3((a.njobs + 7) / 8 * 8), dim3(64 * nwaves), lds, s, a);
+    const dim3 grid((used * midw::kJobs + 7) / 8 * 8, njobs_);
+    if (nine) TGRU_LAUNCH(gru_mid_wgrad_kernel<96>, grid, dim3(64 * nwaves), lds, s, wb);
+    else TGRU_LAUNCH(gru_mid_wgrad_kernel<0>, grid, dim3(64 * nwaves), lds, s, wb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long na = 3L * H * In, nb = 3L * H * H;
-    const int wblocks = (int)((na + nb + 31) / 32), bblocks = db_part ? (4 * H + 7) / 8 : 0;
-    TGRU_LAUNCH(mid_wgrad_reduce_kernel, dim3(wblocks + bblocks), dim3(256), 0, s, slabs, a.slab_stride, used,
-                dw_ih, na, dw_hh, nb, accumulate, wblocks, db_part, db_rows, H, db_ih, db_hh);
+    const int wblocks = (int)((na + nb + 31) / 32), bblocks = jobs[0].db_part ? (4 * H + 7) / 8 : 0;
+    TGRU_LAUNCH(mid_wgrad_reduce_kernel, dim3(wblocks + bblocks, njobs_), dim3(256), 0, s, rb, accumulate, wblocks, H);
     return hipGetLastError();
+}
+
+hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
+                                const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
+                                int accumulate, const float *db_part, int db_rows, float *db_ih, float *db_hh,
+                                hipStream_t s) {
+    const MidWgradJob j{dg, xin, In, x_bt, y, h0, slabs, dw_ih, dw_hh, db_part, db_rows, db_ih, db_hh};
+    return launch_gru_mid_wgrad_batch(&j, 1, B, T, H, accumulate, s);
 }
 
 }  // namespace tgru

@@ -160,13 +160,18 @@ float *fwd_ws_status(const Dims &d, float *ws) {
 
 
 // backward workspace: dg | 2 x dy ping-pong | packed W_hh^T | bias partials | split-K slabs
-struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, status, total; int max_slabs; };
+struct BwdWs { size_t dg, dyb, wtp, dbp, slabs, carry, status, total; int max_slabs;
+               size_t dg_stride, dbp_stride, slabs_stride; };      // per layer on the mid-H path (0: one buffer for all layers)
 BwdWs bwd_ws(const Dims &d) {
     BwdWs w;
     size_t off = 0;
     // the whole-stack path keeps one dg buffer per layer (sized for it regardless of the env switch)
     const bool small_shape = d.H <= kSmallMaxH && d.In <= kSmallMaxIn && d.L <= kSmallMaxL;
-    w.dg = off; off += (small_shape ? (size_t)d.L : 1) * align64(d.TB() * 4 * d.H);
+    // the mid-H path keeps dg, the bias partials and the weight-gradient slabs of every layer until the end of the
+    // call: the layers' weight gradients then go as one launch
+    const bool mid_layers = !small_shape && gru_mid_supported(d.H) && d.L <= kMidWgradMaxLayers;
+    w.dg_stride = mid_layers ? align64(d.TB() * 4 * d.H) : 0;
+    w.dg = off; off += (small_shape || mid_layers ? (size_t)d.L : 1) * align64(d.TB() * 4 * d.H);
     w.dyb = off; off += 2 * align64(d.TB() * (size_t)(d.H > d.In ? d.H : d.In));
     w.wtp = off; off += align64(packed_whh_floats(d.H));
     size_t nblk = (size_t)gru_batch_blocks(d.B);
@@ -174,7 +179,8 @@ BwdWs bwd_ws(const Dims &d) {
     if (vec_shape && (size_t)gru_vec_workgroups(d.B) > nblk) nblk = (size_t)gru_vec_workgroups(d.B);
     if (gru_mid_supported(d.H)) nblk = (size_t)d.B;      // those kernels leave one bias partial per sequence
     if (gru_step_supported(d.B, d.H) && (size_t)gru_step_bias_rows(d.B) > nblk) nblk = (size_t)gru_step_bias_rows(d.B);
-    w.dbp = off; off += align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
+    w.dbp_stride = mid_layers ? align64(nblk * 4 * d.H) : 0;
+    w.dbp = off; off += mid_layers ? (size_t)d.L * w.dbp_stride : align64(nblk * 4 * d.H * (small_shape ? d.L : 1));
     int kc;
     const int widest = d.In > d.H ? d.In : d.H;
     int ns = gemm_split_for(3 * d.H, widest, (long)d.TB(), &kc);
@@ -196,7 +202,8 @@ BwdWs bwd_ws(const Dims &d) {
         const size_t need = (size_t)gru_mid_wgrad_workgroups(d.B, d.T) * gru_mid_wgrad_slab_floats(widest_in, d.H);
         if (need > slab_floats) slab_floats = need;
     }
-    w.slabs = off; off += align64(slab_floats);
+    w.slabs_stride = mid_layers ? align64(slab_floats) : 0;
+    w.slabs = off; off += (mid_layers ? (size_t)d.L : 1) * align64(slab_floats);
     w.carry = off; off += gru_step_supported(d.B, d.H) ? align64((size_t)d.B * d.H) : 0;   // per-step kernels only
     w.status = off; off += kStepStatusFloats;      // error word of the persistent H > 128 kernels
     w.total = off;
@@ -576,10 +583,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     hipStream_t s = (hipStream_t)stream;
     const Dims d{B, T, In, H, L, layout};
     const BwdWs w = bwd_ws(d);
-    float *dg = workspace + w.dg;
     float *wtp = workspace + w.wtp;
-    float *dbp = workspace + w.dbp;
-    float *slabs = workspace + w.slabs;
     const size_t dyb_stride = align64(d.TB() * (size_t)(H > In ? H : In));
     float *res = const_cast<float *>(reserve);
     const int nblk = gru_batch_blocks(B);
@@ -604,8 +608,14 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
     // persistent H > 128 kernels: the call's error word starts at zero
     unsigned *err = use_step(B, H) && gru_step_persistent(B, H) ? reinterpret_cast<unsigned *>(workspace + w.status) : nullptr;
     if (err) TGRU_HIP(gru_step_begin(err, s));
+    MidWgradJob wjobs[kMidWgradMaxLayers];      // mid-H layers whose weight gradients wait for the end of the call
+    int nwjobs = 0;
     for (int l = L - 1; l >= 0; --l) {
         const int In_l = l == 0 ? In : H;
+        // (per-layer buffers on the mid-H path, the shared ones elsewhere)
+        float *dg = workspace + w.dg + (size_t)l * w.dg_stride;
+        float *dbp = workspace + w.dbp + (size_t)l * w.dbp_stride;
+        float *slabs = workspace + w.slabs + (size_t)l * w.slabs_stride;
         const bool top = l == L - 1;
         const float *y_l = (top && layout == TGRU_LAYOUT_TBF) ? y : reserve_y(d, res, l);
         const float *in = l == 0 ? x : reserve_y(d, res, l - 1);
@@ -642,9 +652,12 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
         if (!want_w) {
             // nothing: dg only feeds dX below
         } else if (mid_wgrad) {       // the weight-gradient reduction sums the bias partials in the same launch
-            TGRU_HIP(launch_gru_mid_wgrad(dg, in, In_l, l == 0 && layout == TGRU_LAYOUT_BTF, y_l,
-                                          h0 ? h0 + (size_t)l * B * H : nullptr, slabs, dw_ih[l], dw_hh[l], B, T,
-                                          H, accumulate, dbp, db_rows, db_ih[l], db_hh[l], s));
+            const MidWgradJob job{dg, in, In_l, l == 0 && layout == TGRU_LAYOUT_BTF, y_l,
+                                  h0 ? h0 + (size_t)l * B * H : nullptr, slabs, dw_ih[l], dw_hh[l],
+                                  dbp, db_rows, db_ih[l], db_hh[l]};
+            // with buffers of its own the layer joins the stack's one launch after the loop (same input width only)
+            if (w.dg_stride && (nwjobs == 0 || wjobs[0].In == In_l)) wjobs[nwjobs++] = job;
+            else TGRU_HIP(launch_gru_mid_wgrad_batch(&job, 1, B, T, H, accumulate, s));
         } else {
             TGRU_HIP(launch_bias_grad(dbp, db_rows, H, db_ih[l], db_hh[l], accumulate, s));
         }
@@ -696,6 +709,7 @@ int tgru_backward(const float *dy, const float *dh_n, const float *x, const floa
             TGRU_HIP(launch_gemm(g, true, false, 1, s));
         }
     }
+    if (nwjobs) TGRU_HIP(launch_gru_mid_wgrad_batch(wjobs, nwjobs, B, T, H, accumulate, s));
     if (err) {     // a wait that gave up: NaN at the head of every gradient of the call
         float *outs[8] = {dx, dh0, want_w ? dw_ih[0] : nullptr, want_w ? dw_hh[0] : nullptr,
                           want_w ? db_ih[0] : nullptr, want_w ? db_hh[0] : nullptr,

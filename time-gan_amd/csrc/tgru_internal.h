@@ -230,6 +230,15 @@ hipError_t launch_gru_mid_bwd(const BwdArgs &a, hipStream_t s);   // db_part: on
 bool gru_mid_wgrad_supported(int B, int T, int In, int H);
 int gru_mid_wgrad_workgroups(int B, int T);
 long gru_mid_wgrad_slab_floats(int In, int H);
+// The same for up to kMidWgradMaxLayers layers of one stack in ONE launch (+ one reduction): every job with the same
+// In, all with bias partials or none.  Each layer needs its own dg, slabs and bias partials until then.
+constexpr int kMidWgradMaxLayers = 4;
+struct MidWgradJob {
+    const float *dg, *xin; int In, x_bt; const float *y, *h0; float *slabs, *dw_ih, *dw_hh;
+    const float *db_part; int db_rows; float *db_ih, *db_hh;
+};
+hipError_t launch_gru_mid_wgrad_batch(const MidWgradJob *jobs, int njobs, int B, int T, int H, int accumulate,
+                                      hipStream_t s);
 hipError_t launch_gru_mid_wgrad(const float *dg, const float *xin, int In, int x_bt, const float *y,
                                 const float *h0, float *slabs, float *dw_ih, float *dw_hh, int B, int T, int H,
                                 int accumulate, const float *db_part, int db_rows, float *db_ih, float *db_hh,
