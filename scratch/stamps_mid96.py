@@ -12,6 +12,7 @@ r = tg.GRURunner(B, T, H, H, L, tg.LAYOUT_TBF, dev); r.set_weights(make_weights(
 x = torch.rand(T, B, H, device=dev); dy = torch.randn(T, B, H, device=dev)
 for _ in range(3):
     r.forward(x); r.backward(dy)
+r.forward(x)          # (the backward kernel writes the same stamp array: the forward kernel runs last)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
 lb = _lib.lib()
@@ -21,4 +22,5 @@ a = np.array(out[:], dtype=np.float64) / T
 names = ['0 loop top', '1 (after product)', '2 barrier A', '3 gates | input rows', '4 barrier B', '5 product: reads + MFMAs', '6 product: reduce + stores', '7']
 for k in range(7):
     print(f'{names[k]:24s} wave 0 {a[k]:8.0f}   wave 5 {a[8 + k]:8.0f}  cycles/step')
-print('sum', a[:8].sum(), a[8:].sum())
+print('sum', a[:7].sum(), a[8:15].sum())
+print('prologue (kernel start -> matrix rows in registers), cycles: wave 0', a[7] * T, ' wave 5', a[15] * T)

@@ -67,6 +67,9 @@ extern "C" int tgru_debug_stamps_mid96(unsigned long long *out) {
 
 __global__ __launch_bounds__(64 * m96::kWaves) void gru_mid96_fwd_kernel(FwdArgs a) {
     using namespace m96;
+#ifdef TGRU_STAMPS
+    const unsigned long long st_kernel0 = __builtin_amdgcn_s_memtime();
+#endif
     // hs[2][kSeq][HS] | gh[kMain + kPart] | gi[kMain + kPart] | xs[kSeq][H]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int B = a.B, T = a.T;
@@ -121,6 +124,11 @@ __global__ __launch_bounds__(64 * m96::kWaves) void gru_mid96_fwd_kernel(FwdArgs
     }
     const int jl = lane & 3, bl = lane >> 2;
     FSTAMP_DECL
+#ifdef TGRU_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (slot 7: the prologue, matrix rows in registers)
+    st_acc[7] = __builtin_amdgcn_s_memtime() - st_kernel0;
+    st_last = __builtin_amdgcn_s_memtime();
+#endif
     // out[kMain | kPart] = M . v for the four vectors v (`vec`: this lane's sequence jl), M the wave set's matrix.
     // Lane 4b+i gives A_b[i] = its row's element k, lane 4b+j gives B_b[j] = v_j[k]; register i of lane 4b+j
     // receives rows 4b .. 4b+3 of sequence j.  The vector's 16-byte reads are kept a few pieces ahead of the
